@@ -1,0 +1,292 @@
+/*
+ * rt_amd.h — C ABI of the MI355X path tracer (librt_amd.so).
+ *
+ * Two halves:
+ *
+ *  (1) Scene surface (host only, no GPU touched). Keeps the reference's scene
+ *      surface: the AoS structs of src/vk_engine.h:49-79,117-123,145-189 with
+ *      the same field names and std140 / push-constant layouts,
+ *      and the scene builders of src/vk_engine.cpp (read_obj :800-1037,
+ *      read_mtl :1060-1167, cornell_box :638-678, prepare_storage_buffers
+ *      :680-758, build_bvh :1169-1337, camera matrix of run_compute
+ *      :1631-1661).
+ *
+ *  (2) Device half. Replaces the Vulkan seam of the reference:
+ *        copy_buffer   (src/vk_engine.cpp:1401-1444)  -> rt_upload_scene
+ *        update_buffer (src/vk_engine.cpp:1446-1475)  -> rt_update_*
+ *        run_compute   (src/vk_engine.cpp:1623-1676)  -> rt_render
+ *      The per-pixel megakernel shaders/raytrace.comp is replaced by a
+ *      wavefront pipeline of HIP kernels for gfx950.
+ *
+ * All entry points are extern "C", take plain pointers and sizes, return an
+ * int status (0 = ok, <0 = error; message via rt_last_error) and never abort
+ * (the reference's VK_CHECK aborts, src/vk_engine.cpp:20-27).
+ * A ctx is bound to one GPU and is not thread-safe; one process per GPU.
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Scene structs — byte-compatible with the reference's host structs   */
+/* ------------------------------------------------------------------ */
+
+/* src/vk_engine.h:49-53 (std140, 32 B) */
+typedef struct Sphere {
+    float position[3];
+    float radius;            /* @12 */
+    uint32_t materialIndex;  /* @16 */
+    uint32_t _pad[3];
+} Sphere;
+
+/* src/vk_engine.h:55-62 (48 B). binormal/tangent are never initialised by
+ * the reference (calculate_binormal assigns nothing) and never read. */
+typedef struct Triangle {
+    uint32_t v0, v1, v2;
+    uint32_t frontOnly;
+    float binormal[3]; float _pad0; /* @16 */
+    float tangent[3];  float _pad1; /* @32 */
+} Triangle;
+
+/* src/vk_engine.h:64-67 (32 B): uv.x is position.w, uv.y is normal.w */
+typedef struct TrianglePoint {
+    float position[4];
+    float normal[4];
+} TrianglePoint;
+
+/* src/vk_engine.h:69-79 (64 B) */
+typedef struct RayMaterial {
+    float albedo[3]; float _pad0;  /* @0  default (1,1,1) */
+    float emissionColor[3];        /* @16 default (0,0,0) */
+    float emissionStrength;        /* @28 */
+    float reflectance;             /* @32 */
+    float ior;                     /* @36 default -1 */
+    int32_t albedoIndex;           /* @40 default -1 */
+    int32_t metalnessIndex;        /* @44 */
+    int32_t alphaIndex;            /* @48 */
+    int32_t bumpIndex;             /* @52 */
+    uint32_t _pad1[2];
+} RayMaterial;
+
+/* src/vk_engine.h:117-123 (80 B); transformMatrix is column-major */
+typedef struct RenderObject {
+    float transformMatrix[16];
+    uint32_t smoothShade;    /* @64 */
+    uint32_t bvhIndex;       /* @68 */
+    uint32_t materialIndex;  /* @72 */
+    uint32_t samplerIndex;   /* @76 */
+} RenderObject;
+
+/* src/vk_engine.h:185-189 (32 B). triCount == 0: interior, index = left
+ * child, right child = index + 1; else leaf, index = first triangle. */
+typedef struct BVHNode {
+    float boundsX[2], boundsY[2], boundsZ[2]; /* (min,max) per axis */
+    uint32_t index, triCount;
+} BVHNode;
+
+/* src/vk_engine.h:145-151 (96 B) */
+typedef struct CameraInfo {
+    float cameraRotation[16];
+    float pos[3];            /* @64 default (0,-0.5,-3.5) */
+    float nearPlane;         /* @76 default 0.1 */
+    float aspectRatio;       /* @80 */
+    float fov;               /* @84 default 50 */
+    float _pad[2];
+} CameraInfo;
+
+/* src/vk_engine.h:153-158 (64 B) */
+typedef struct EnvironmentData {
+    float horizonColor[4];   /* w = sun focus */
+    float zenithColor[4];    /* w = sun intensity */
+    float groundColor[3]; float _pad0;
+    float lightDir[4];       /* w = environment on */
+} EnvironmentData;
+
+/* src/vk_engine.h:160-171 (40 B); the two bools occupy 4-byte slots */
+typedef struct RayTracerData {
+    uint32_t progressive;
+    uint32_t singleRender;
+    int32_t debug;           /* -1 off, 0 box heat map, 1 tri heat map, 2 both */
+    uint32_t raysPerPixel;
+    uint32_t bounceLimit;
+    uint32_t sphereCount;
+    uint32_t objectCount;
+    uint32_t triangleCap;
+    uint32_t boxCap;
+    uint32_t sampleLimit;
+} RayTracerData;
+
+/* src/vk_engine.h:173-178 (208 B) */
+typedef struct PushConstants {
+    CameraInfo camInfo;          /* @0   */
+    EnvironmentData environment; /* @96  */
+    RayTracerData rayTraceParams;/* @160 */
+    uint32_t frameCount;         /* @200 */
+    uint32_t _pad;
+} PushConstants;
+
+/* src/vk_engine.h:125-132 (the placement half of ImGuiObject) */
+typedef struct RtPlacement {
+    float position[3];
+    float rotation[3];       /* Euler degrees, applied T*Rx*Ry*Rz*S */
+    float scale[3];
+    uint32_t samplerIndex;
+    uint32_t frontOnly;
+} RtPlacement;
+
+enum { RT_MAX_TEXTURES = 64, RT_MAX_MATERIALS = 10, RT_MAX_SPHERES = 10, RT_BVH_BINS = 20 };
+
+/* Borrowed views of the scene's host vectors (VulkanEngine members
+ * spheres / rayMaterials / triPoints / triangles / objects / bvhNodes,
+ * src/vk_engine.h:270-283). */
+typedef struct RtSceneArrays {
+    const Sphere* spheres;              uint32_t sphereCount;
+    const RayMaterial* materials;       uint32_t materialCount;
+    const TrianglePoint* triPoints;     uint32_t triPointCount;
+    const Triangle* triangles;          uint32_t triangleCount;
+    const RenderObject* objects;        uint32_t objectCount;
+    const BVHNode* bvhNodes;            uint32_t bvhNodeCount;
+} RtSceneArrays;
+
+/* ------------------------------------------------------------------ */
+/* (1) Scene surface — host only                                        */
+/* ------------------------------------------------------------------ */
+typedef struct rt_scene rt_scene;
+
+int  rt_scene_create(rt_scene** out);
+void rt_scene_destroy(rt_scene* s);
+const char* rt_scene_last_error(const rt_scene* s);
+
+/* rayMaterials.push_back (src/vk_engine.cpp:717-722); returns the index or <0 */
+int  rt_scene_add_material(rt_scene* s, const RayMaterial* m);
+/* a default-constructed RayMaterial (src/vk_engine.h:69-79) */
+void rt_material_default(RayMaterial* m);
+/* spheres[i] = ... (src/vk_engine.cpp:682-686); i < RT_MAX_SPHERES */
+int  rt_scene_set_sphere(rt_scene* s, uint32_t i, const float position[3], float radius, uint32_t materialIndex);
+void rt_placement_default(RtPlacement* p);
+
+/* VulkanEngine::read_obj (src/vk_engine.cpp:800-1037). `material` is the
+ * fallback material index for files without usemtl. A missing file is a
+ * silent no-op returning 1 (the reference returns silently, :834). */
+int  rt_scene_read_obj(rt_scene* s, const char* filePath, const RtPlacement* placement, int material);
+/* VulkanEngine::read_mtl (src/vk_engine.cpp:1060-1167) without the image
+ * uploads: map_* lines only claim texture slots (textures are never sampled
+ * by the shader at this snapshot). */
+int  rt_scene_read_mtl(rt_scene* s, const char* filePath);
+/* A programmatic mesh goes through the same triangle/centroid/BVH path as an
+ * OBJ group. positions/normals: 9 floats per triangle (corner-major);
+ * uvs: 6 floats per triangle or NULL. */
+int  rt_scene_add_mesh(rt_scene* s, const char* key, const float* positions, const float* normals,
+                       const float* uvs, uint32_t triCount, const RtPlacement* placement, int material);
+/* VulkanEngine::cornell_box (src/vk_engine.cpp:638-678); assetDir holds
+ * light2.obj, plane.obj, ceiling.obj */
+int  rt_scene_cornell_box(rt_scene* s, const char* assetDir);
+/* VulkanEngine::prepare_storage_buffers (src/vk_engine.cpp:680-758): ten
+ * zeroed spheres, the six built-in materials, the two cubes, cornell_box. */
+int  rt_scene_prepare_default(rt_scene* s, const char* assetDir);
+int  rt_scene_get_arrays(const rt_scene* s, RtSceneArrays* out);
+/* index of a material loaded from an MTL file, key "<mtlpath>/<name>"; -1 if absent */
+int  rt_scene_find_material(const rt_scene* s, const char* key);
+/* BVH build statistics of the most recent build (printed by the reference, :1187-1193) */
+int  rt_scene_last_bvh_stats(const rt_scene* s, uint32_t* nodeCount, uint32_t* maxDepth, uint32_t* minDepth, uint32_t* maxTri);
+
+/* Camera/constants half of run_compute (src/vk_engine.cpp:1631-1661):
+ * cameraRotation = rotY * rotX * rotZ from Euler degrees. */
+void rt_camera_rotation(const float anglesDeg[3], float outMat4[16]);
+/* defaults of src/vk_engine.h:145-171,325 (angles {4,0,0}) with aspect = W/H */
+void rt_push_constants_default(PushConstants* pc, uint32_t width, uint32_t height);
+/* object.transformMatrix = T*Rx*Ry*Rz*S (src/vk_engine.cpp:1012-1016) */
+void rt_transform_matrix(const RtPlacement* p, float outMat4[16]);
+
+/* ------------------------------------------------------------------ */
+/* (2) Device half                                                      */
+/* ------------------------------------------------------------------ */
+typedef struct rt_ctx rt_ctx;
+
+/* Global counters summed over every closest-hit query the device executed
+ * since the last rt_reset_counters. */
+typedef struct RtCounters {
+    uint64_t boxTests;      /* reference stats[0] semantics, raytrace.comp:338, all queries */
+    uint64_t triTests;      /* reference stats[1] semantics, raytrace.comp:310, all queries */
+    uint64_t raysTraced;    /* closest-hit queries executed on the device (unique rays) */
+    uint64_t raysHit;       /* of those, queries that reported a hit */
+    uint64_t raysReference; /* queries the reference megakernel would have issued for the same paths */
+    uint64_t paths;         /* trace() calls finished (pixel samples) */
+    uint64_t segments;      /* path segments shaded */
+    uint64_t traceLaunches; /* launches of the traversal kernel */
+} RtCounters;
+
+/* One closest-hit record of calculateIntersections (raytrace.comp:276-353) */
+typedef struct RtHit {
+    float dst;              /* RT_MISS_DST on miss */
+    uint32_t didHit;
+    uint32_t isSphere;
+    uint32_t objectHitIndex;/* object index, or sphere index when isSphere */
+    uint32_t triHitIndex;
+    uint32_t materialIndex;
+    uint32_t frontFace;
+    float hitPoint[3];
+    float normal[3];
+    uint32_t boxTests;      /* this query's stats[0] */
+    uint32_t triTests;      /* this query's stats[1] */
+} RtHit;
+
+int  rt_device_count(int* out);
+int  rt_create(int device, rt_ctx** out);
+void rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx);
+/* use an existing hipStream_t (e.g. torch's current stream); NULL = ctx's own */
+int  rt_set_stream(rt_ctx* ctx, void* hipStream);
+
+/* copy_buffer x6 (src/vk_engine.cpp:686,753-757): takes the reference's AoS
+ * host arrays, converts to the device layouts, uploads. Borrowed for the call. */
+int  rt_upload_scene(rt_ctx* ctx, const RtSceneArrays* scene);
+/* update_buffer (src/vk_engine.cpp:1545,1572,1603) */
+int  rt_update_materials(rt_ctx* ctx, const RayMaterial* m, uint32_t n);
+int  rt_update_spheres(rt_ctx* ctx, const Sphere* s, uint32_t n);
+int  rt_update_objects(rt_ctx* ctx, const RenderObject* o, uint32_t n);
+
+/* run_compute: one dispatch of the path tracer over rows
+ * y = row0 + k*rowStride, k in [0,nRows) of a width x height image, using the
+ * global pixel index for the RNG seed so any tiling gives identical pixels.
+ * samples per pixel = singleRender ? sampleLimit : raysPerPixel (:570).
+ * d_rgba: device pointer to nRows*width*4 floats (RGBA fp32, before any 8-bit
+ * step), or NULL to use the ctx's own framebuffer (rt_read_rgba_f32).
+ * Asynchronous on the ctx stream; rt_sync waits. */
+int  rt_render(rt_ctx* ctx, const PushConstants* pc, uint32_t width, uint32_t height,
+               uint32_t row0, uint32_t rowStride, uint32_t nRows, float* d_rgba);
+int  rt_sync(rt_ctx* ctx);
+/* copies the ctx's own framebuffer of the last rt_render(…, NULL) to host */
+int  rt_read_rgba_f32(rt_ctx* ctx, float* hostOut, size_t nFloats);
+/* 8-bit sRGB-encoded RGBA of the same framebuffer (the reference's display format) */
+int  rt_read_rgba8_srgb(rt_ctx* ctx, uint8_t* hostOut, size_t nBytes);
+
+/* calculateIntersections for n caller-supplied rays (host arrays, 3 floats
+ * each), for kernel-level parity tests. Synchronous. */
+int  rt_trace_rays(rt_ctx* ctx, uint32_t n, const float* origins, const float* dirs, RtHit* hitsOut);
+
+int  rt_get_counters(rt_ctx* ctx, RtCounters* out);
+int  rt_reset_counters(rt_ctx* ctx);
+/* When enabled, every traversal-kernel launch is bracketed by HIP events on
+ * the launch stream; rt_get_trace_time_ms returns their summed duration and
+ * launch count since the last reset (synchronises). */
+int  rt_set_profiling(rt_ctx* ctx, int enabled);
+int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
+/* device self-test of the deterministic-math build (must equal RT_SELFTEST_EXPECT) */
+int  rt_device_selftest(rt_ctx* ctx, uint32_t* bitsOut);
+uint32_t rt_host_selftest(void);
+/* streaming-copy ceiling measured on this GPU (GB/s), quoted beside the 8 TB/s nominal */
+int  rt_measure_copy_bandwidth(rt_ctx* ctx, size_t bytes, int iters, double* gbpsOut);
+
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

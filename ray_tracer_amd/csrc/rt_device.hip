@@ -1,0 +1,703 @@
+// rt_device.hip — device half of the C ABI: context, uploads, the wavefront
+// render loop. Replaces the Vulkan seam of the reference (copy_buffer /
+// update_buffer / run_compute, src/vk_engine.cpp:1401-1475,1623-1676) with
+// hipMalloc'd buffers and HIP launches on one stream per context.
+//
+// There is no CPU fallback anywhere in this file: without a HIP device
+// rt_create fails and nothing else can be called.
+
+#include "rt_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct EventPair { hipEvent_t a, b; };
+// device-side {index,triCount} of a mesh root, keyed by its reference node index
+struct RootInfo { uint32_t idx, cnt; };
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    // scene
+    DevScene sc{};
+    std::vector<DevBuf> sceneBufs;
+    DevBuf matBuf, sphereBuf, sphereMatBuf, objInvBuf, objFwdBuf, objMetaBuf;
+    uint32_t maxLeafDepth = 0;
+    std::vector<uint32_t> nodeRemap;          // reference node index -> device node index
+    std::vector<RootInfo> rootOf;             // per reference node; idx = ~0u unless a mesh root
+
+    // path state
+    DevBuf stateBuf, queueBuf, fbBuf, counterBuf, scratchBuf;
+    uint32_t capacity = 0;  // pixels the state buffers hold
+    PathState ps{};
+    Queues q{};
+    uint32_t* hostCounts = nullptr;  // pinned, 4 words
+    uint32_t fbPixels = 0;
+    bool fbValid = false;
+
+    // profiling of the traversal kernel
+    bool profiling = false;
+    std::vector<EventPair> evPool;
+    size_t evUsed = 0;
+    double traceMs = 0.0;
+    uint64_t traceLaunches = 0;
+    uint64_t traceLaunchesTotal = 0;
+
+    int fail(const std::string& m) { error = m; return -1; }
+    int hip(hipError_t e, const char* what) {
+        if (e == hipSuccess) return 0;
+        error = std::string(what) + ": " + hipGetErrorString(e);
+        return -(int)e - 1000;
+    }
+};
+
+#define RT_HIP(ctx, call)                                    \
+    do {                                                     \
+        int _rc = (ctx)->hip((call), #call);                 \
+        if (_rc) return _rc;                                 \
+    } while (0)
+
+namespace {
+
+int dev_alloc(rt_ctx* c, DevBuf& b, size_t bytes) {
+    if (b.p && b.bytes >= bytes) return 0;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.bytes = 0; }
+    if (bytes == 0) bytes = 256;
+    RT_HIP(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return 0;
+}
+void dev_free(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.bytes = 0;
+}
+
+int upload(rt_ctx* c, DevBuf& b, const void* src, size_t bytes) {
+    int rc = dev_alloc(c, b, bytes);
+    if (rc) return rc;
+    if (bytes) RT_HIP(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));  // src is borrowed for the call only
+    return 0;
+}
+
+void pack_materials(const RayMaterial* m, uint32_t n, std::vector<float4>& out) {
+    out.resize((size_t)std::max(n, 1u) * 3);
+    for (uint32_t i = 0; i < n; i++) {
+        out[3 * i + 0] = make_float4(m[i].albedo[0], m[i].albedo[1], m[i].albedo[2], m[i].reflectance);
+        out[3 * i + 1] = make_float4(m[i].emissionColor[0], m[i].emissionColor[1], m[i].emissionColor[2], m[i].emissionStrength);
+        out[3 * i + 2] = make_float4(m[i].ior, 0.f, 0.f, 0.f);
+    }
+}
+
+// rows 0..2 of a column-major mat4
+void rows_of(const float* m, float4* out) {
+    for (int r = 0; r < 3; r++) out[r] = make_float4(m[0 + r], m[4 + r], m[8 + r], m[12 + r]);
+}
+
+int ensure_state(rt_ctx* c, uint32_t nPixels) {
+    if (c->capacity >= nPixels && c->stateBuf.p) return 0;
+    const size_t stride = (((size_t)nPixels * 4) + 255) & ~(size_t)255;  // bytes per array
+    const int nArrays = 49;
+    int rc = dev_alloc(c, c->stateBuf, stride * nArrays);
+    if (rc) return rc;
+    char* base = (char*)c->stateBuf.p;
+    int k = 0;
+    auto nextf = [&]() { return (float*)(base + stride * (k++)); };
+    auto nextu = [&]() { return (uint32_t*)(base + stride * (k++)); };
+    PathState& ps = c->ps;
+    for (int i = 0; i < 3; i++) ps.rayO[i] = nextf();
+    for (int i = 0; i < 3; i++) ps.rayD[i] = nextf();
+    for (int i = 0; i < 3; i++) ps.auxO[i] = nextf();
+    for (int i = 0; i < 3; i++) ps.auxDL[i] = nextf();
+    for (int i = 0; i < 3; i++) ps.auxDC[i] = nextf();
+    for (int i = 0; i < 3; i++) ps.hitT[i] = nextf();
+    for (int i = 0; i < 3; i++) ps.hitObj[i] = nextu();
+    ps.hitTri = nextu();
+    for (int i = 0; i < 3; i++) ps.att[i] = nextf();
+    for (int i = 0; i < 3; i++) ps.total[i] = nextf();
+    for (int i = 0; i < 3; i++) ps.direct[i] = nextf();
+    ps.misW = nextf();
+    for (int i = 0; i < 3; i++) ps.pendAlbedo[i] = nextf();
+    ps.pendNDotL = nextf();
+    ps.pendCosPdfL = nextf();
+    ps.pendCosPdfC = nextf();
+    for (int i = 0; i < 3; i++) ps.accum[i] = nextf();
+    ps.rng = nextu();
+    ps.sample = nextu();
+    ps.bounce = nextu();
+    ps.statBox = nextu();
+    ps.statTri = nextu();
+    if (k != nArrays) return c->fail("internal: path state array count");
+
+    // queues: 2 x active (n) + 2 x rays (3n) + 4 counters
+    const size_t qa = (((size_t)nPixels * 4) + 255) & ~(size_t)255;
+    const size_t qr = (((size_t)nPixels * 3 * 4) + 255) & ~(size_t)255;
+    rc = dev_alloc(c, c->queueBuf, 2 * qa + 2 * qr + 256);
+    if (rc) return rc;
+    char* qb = (char*)c->queueBuf.p;
+    c->q.active[0] = (uint32_t*)qb;
+    c->q.active[1] = (uint32_t*)(qb + qa);
+    c->q.rays[0] = (uint32_t*)(qb + 2 * qa);
+    c->q.rays[1] = (uint32_t*)(qb + 2 * qa + qr);
+    c->q.counts = (uint32_t*)(qb + 2 * qa + 2 * qr);
+    c->capacity = nPixels;
+    return 0;
+}
+
+template <int STACK>
+void launch_trace_t(rt_ctx* c, uint32_t blocks, const TraceArgs& ta) {
+    hipLaunchKernelGGL((k_trace<STACK>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, ta);
+}
+
+int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
+    if (maxRays == 0) return 0;
+    uint32_t blocks = (maxRays + RT_BLOCK - 1) / RT_BLOCK;
+    EventPair* ev = nullptr;
+    if (c->profiling) {
+        if (c->evUsed == c->evPool.size()) {
+            EventPair p;
+            RT_HIP(c, hipEventCreate(&p.a));
+            RT_HIP(c, hipEventCreate(&p.b));
+            c->evPool.push_back(p);
+        }
+        ev = &c->evPool[c->evUsed++];
+        RT_HIP(c, hipEventRecord(ev->a, c->stream));
+    }
+    const uint32_t d = c->maxLeafDepth;
+    if (d <= 8) launch_trace_t<8>(c, blocks, ta);
+    else if (d <= 16) launch_trace_t<16>(c, blocks, ta);
+    else if (d <= 24) launch_trace_t<24>(c, blocks, ta);
+    else if (d <= 32) launch_trace_t<32>(c, blocks, ta);
+    else if (d <= 48) launch_trace_t<48>(c, blocks, ta);
+    else launch_trace_t<64>(c, blocks, ta);
+    RT_HIP(c, hipGetLastError());
+    if (ev) RT_HIP(c, hipEventRecord(ev->b, c->stream));
+    c->traceLaunchesTotal++;
+    return 0;
+}
+
+// sum finished event pairs; the stream must be idle
+int harvest_events(rt_ctx* c) {
+    for (size_t i = 0; i < c->evUsed; i++) {
+        float ms = 0.f;
+        RT_HIP(c, hipEventElapsedTime(&ms, c->evPool[i].a, c->evPool[i].b));
+        c->traceMs += ms;
+        c->traceLaunches++;
+    }
+    c->evUsed = 0;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_device_count(int* out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (out) *out = (e == hipSuccess) ? n : 0;
+    return e == hipSuccess ? 0 : -1;
+}
+
+int rt_create(int device, rt_ctx** out) {
+    if (!out) return -1;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -2;  // no GPU: fail loudly, no fallback
+    if (device < 0 || device >= n) return -3;
+    if (hipSetDevice(device) != hipSuccess) return -4;
+    rt_ctx* c = new rt_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { delete c; return -5; }
+    c->stream = c->ownStream;
+    if (hipHostMalloc((void**)&c->hostCounts, 64, hipHostMallocDefault) != hipSuccess) { delete c; return -6; }
+    if (dev_alloc(c, c->counterBuf, sizeof(DevCounters)) != 0) { delete c; return -7; }
+    (void)hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters), c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    *out = c;
+    return 0;
+}
+
+void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& b : c->sceneBufs) dev_free(b);
+    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->stateBuf,
+                      &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf})
+        dev_free(*b);
+    for (auto& e : c->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (c->hostCounts) (void)hipHostFree(c->hostCounts);
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    delete c;
+}
+
+const char* rt_last_error(const rt_ctx* c) { return c ? c->error.c_str() : "null ctx"; }
+
+int rt_set_stream(rt_ctx* c, void* s) {
+    if (!c) return -1;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->ownStream;
+    return 0;
+}
+
+int rt_update_materials(rt_ctx* c, const RayMaterial* m, uint32_t n) {
+    if (!c || (!m && n)) return -1;
+    RT_HIP(c, hipSetDevice(c->device));
+    std::vector<float4> packed;
+    pack_materials(m, n, packed);
+    int rc = upload(c, c->matBuf, packed.data(), packed.size() * sizeof(float4));
+    if (rc) return rc;
+    c->sc.mats = (const float4*)c->matBuf.p;
+    c->sc.materialCount = n;
+    return 0;
+}
+
+int rt_update_spheres(rt_ctx* c, const Sphere* s, uint32_t n) {
+    if (!c || (!s && n)) return -1;
+    RT_HIP(c, hipSetDevice(c->device));
+    std::vector<float4> sp(std::max(n, 1u));
+    std::vector<uint32_t> sm(std::max(n, 1u));
+    for (uint32_t i = 0; i < n; i++) {
+        sp[i] = make_float4(s[i].position[0], s[i].position[1], s[i].position[2], s[i].radius);
+        sm[i] = s[i].materialIndex;
+    }
+    int rc = upload(c, c->sphereBuf, sp.data(), sp.size() * sizeof(float4));
+    if (rc) return rc;
+    rc = upload(c, c->sphereMatBuf, sm.data(), sm.size() * 4);
+    if (rc) return rc;
+    c->sc.spheres = (const float4*)c->sphereBuf.p;
+    c->sc.sphereMat = (const uint32_t*)c->sphereMatBuf.p;
+    c->sc.sphereCount = n;
+    return 0;
+}
+
+// objects: inverse computed once on the host with the shared
+// rt_mat4_inverse, root metadata resolved against the uploaded BVH.
+int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
+    if (!c || (!o && n)) return -1;
+    if (c->rootOf.empty() && n) return c->fail("rt_update_objects before rt_upload_scene");
+    RT_HIP(c, hipSetDevice(c->device));
+    std::vector<float4> inv((size_t)std::max(n, 1u) * 3), fwd((size_t)std::max(n, 1u) * 3);
+    std::vector<uint4> meta(std::max(n, 1u));
+    for (uint32_t i = 0; i < n; i++) {
+        float im[16];
+        rt_mat4_inverse(o[i].transformMatrix, im);
+        rows_of(im, &inv[3 * (size_t)i]);
+        rows_of(o[i].transformMatrix, &fwd[3 * (size_t)i]);
+        if (o[i].bvhIndex >= c->rootOf.size()) return c->fail("object.bvhIndex out of range");
+        const RootInfo& r = c->rootOf[o[i].bvhIndex];
+        if (r.idx == 0xffffffffu) return c->fail("object.bvhIndex does not point at a mesh root of the uploaded BVH");
+        if (o[i].materialIndex >= std::max(c->sc.materialCount, 1u)) return c->fail("object.materialIndex out of range");
+        meta[i] = make_uint4(r.idx, r.cnt, o[i].materialIndex, o[i].bvhIndex);
+    }
+    int rc = upload(c, c->objInvBuf, inv.data(), inv.size() * sizeof(float4));
+    if (rc) return rc;
+    if ((rc = upload(c, c->objFwdBuf, fwd.data(), fwd.size() * sizeof(float4)))) return rc;
+    if ((rc = upload(c, c->objMetaBuf, meta.data(), meta.size() * sizeof(uint4)))) return rc;
+    c->sc.objInv = (const float4*)c->objInvBuf.p;
+    c->sc.objFwd = (const float4*)c->objFwdBuf.p;
+    c->sc.objMeta = (const uint4*)c->objMetaBuf.p;
+    c->sc.objectCount = n;
+    return 0;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
+    if (!c || !s) return -1;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    const uint32_t nNodes = s->bvhNodeCount, nTris = s->triangleCount;
+
+    // ---- mesh segmentation: every distinct object.bvhIndex starts a mesh
+    std::vector<uint32_t> roots;
+    for (uint32_t i = 0; i < s->objectCount; i++) {
+        if (s->objects[i].bvhIndex >= nNodes) return c->fail("object.bvhIndex out of range");
+        roots.push_back(s->objects[i].bvhIndex);
+    }
+    std::sort(roots.begin(), roots.end());
+    roots.erase(std::unique(roots.begin(), roots.end()), roots.end());
+
+    // ---- device node numbering: shift each mesh so its child pairs (which
+    // follow the root in twos) start on an even index = 64-byte boundary
+    c->nodeRemap.assign(nNodes, 0);
+    uint32_t shift = 0, devCount = 0;
+    {
+        size_t r = 0;
+        for (uint32_t nidx = 0; nidx < nNodes; nidx++) {
+            if (r < roots.size() && roots[r] == nidx) {
+                if (((nidx + shift) & 1u) == 0u) shift++;  // root on an odd slot
+                r++;
+            }
+            c->nodeRemap[nidx] = nidx + shift;
+        }
+        devCount = nNodes + shift;
+    }
+
+    std::vector<float4> nodes((size_t)std::max(devCount, 2u) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (uint32_t nidx = 0; nidx < nNodes; nidx++) {
+        const BVHNode& b = s->bvhNodes[nidx];
+        uint32_t idx = b.index;
+        if (b.triCount == 0) {
+            if (idx + 1 >= nNodes) return c->fail("BVH child index out of range");
+            idx = c->nodeRemap[idx];
+            if (idx & 1u) return c->fail("internal: child pair not 64-byte aligned (BVH not built in pairs)");
+        } else if ((uint64_t)b.index + b.triCount > nTris) {
+            return c->fail("BVH leaf triangle range out of bounds");
+        }
+        float4 lo = make_float4(b.boundsX[0], b.boundsY[0], b.boundsZ[0], 0.f);
+        float4 hi = make_float4(b.boundsX[1], b.boundsY[1], b.boundsZ[1], 0.f);
+        memcpy(&lo.w, &idx, 4);
+        memcpy(&hi.w, &b.triCount, 4);
+        nodes[2 * (size_t)c->nodeRemap[nidx]] = lo;
+        nodes[2 * (size_t)c->nodeRemap[nidx] + 1] = hi;
+    }
+
+    // ---- deepest leaf per mesh decides the LDS stack size
+    std::vector<RootInfo>& rootOf = c->rootOf;
+    rootOf.assign(nNodes, RootInfo{0xffffffffu, 0});
+    uint32_t maxDepth = 0;
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> st;
+        for (uint32_t root : roots) {
+            const BVHNode& rb = s->bvhNodes[root];
+            rootOf[root] = RootInfo{rb.triCount ? rb.index : c->nodeRemap[rb.index], rb.triCount};
+            st.clear();
+            st.emplace_back(root, 0u);
+            size_t visited = 0;
+            while (!st.empty()) {
+                auto [nidx, d] = st.back();
+                st.pop_back();
+                if (++visited > (size_t)nNodes + 1) return c->fail("BVH has a cycle");
+                const BVHNode& b = s->bvhNodes[nidx];
+                if (b.triCount) { maxDepth = std::max(maxDepth, d); continue; }
+                st.emplace_back(b.index, d + 1);
+                st.emplace_back(b.index + 1, d + 1);
+            }
+        }
+    }
+    if (maxDepth > 64) return c->fail("BVH deeper than 64 levels (the reference's builder caps at 64)");
+    c->maxLeafDepth = maxDepth;
+
+    // ---- triangles: positions hot, normals cold, both in the reference's order
+    std::vector<float4> tpos((size_t)std::max(nTris, 1u) * 3), tnrm((size_t)std::max(nTris, 1u) * 3);
+    for (uint32_t t = 0; t < nTris; t++) {
+        const Triangle& tr = s->triangles[t];
+        const uint32_t vi[3] = {tr.v0, tr.v1, tr.v2};
+        for (int k = 0; k < 3; k++) {
+            if (vi[k] >= s->triPointCount) return c->fail("triangle point index out of range");
+            const TrianglePoint& p = s->triPoints[vi[k]];
+            float w = 0.f;
+            if (k == 0) { uint32_t fo = tr.frontOnly ? 1u : 0u; memcpy(&w, &fo, 4); }
+            tpos[3 * (size_t)t + k] = make_float4(p.position[0], p.position[1], p.position[2], w);
+            tnrm[3 * (size_t)t + k] = make_float4(p.normal[0], p.normal[1], p.normal[2], 0.f);
+        }
+    }
+
+    for (auto& b : c->sceneBufs) dev_free(b);
+    c->sceneBufs.assign(3, DevBuf());
+    int rc;
+    if ((rc = upload(c, c->sceneBufs[0], nodes.data(), nodes.size() * sizeof(float4)))) return rc;
+    if ((rc = upload(c, c->sceneBufs[1], tpos.data(), tpos.size() * sizeof(float4)))) return rc;
+    if ((rc = upload(c, c->sceneBufs[2], tnrm.data(), tnrm.size() * sizeof(float4)))) return rc;
+    c->sc.nodes = (const float4*)c->sceneBufs[0].p;
+    c->sc.triPos = (const float4*)c->sceneBufs[1].p;
+    c->sc.triNrm = (const float4*)c->sceneBufs[2].p;
+    c->sc.nodeCount = devCount;
+    c->sc.triCount = nTris;
+
+    if (s->materialCount == 0) return c->fail("scene needs at least one material");
+    if ((rc = rt_update_materials(c, s->materials, s->materialCount))) return rc;
+    for (uint32_t i = 0; i < s->sphereCount; i++)
+        if (s->spheres[i].materialIndex >= s->materialCount) return c->fail("sphere.materialIndex out of range");
+    if ((rc = rt_update_spheres(c, s->spheres, s->sphereCount))) return rc;
+    return rt_update_objects(c, s->objects, s->objectCount);
+}
+
+int rt_sync(rt_ctx* c) {
+    if (!c) return -1;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return harvest_events(c);
+}
+
+int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t height, uint32_t row0, uint32_t rowStride,
+              uint32_t nRows, float* d_rgba) {
+    if (!c || !pc) return -1;
+    if (width == 0 || height == 0 || rowStride == 0) return c->fail("rt_render: bad image geometry");
+    if (nRows && (uint64_t)row0 + (uint64_t)(nRows - 1) * rowStride >= height) return c->fail("rt_render: rows exceed the image");
+    if (!c->sc.nodes) return c->fail("rt_render before rt_upload_scene");
+    const RayTracerData& td = pc->rayTraceParams;
+    if (td.sphereCount > c->sc.sphereCount) return c->fail("rayTraceParams.sphereCount exceeds the uploaded spheres");
+    if (td.objectCount > c->sc.objectCount) return c->fail("rayTraceParams.objectCount exceeds the uploaded objects");
+    const uint64_t np64 = (uint64_t)nRows * width;
+    if (np64 >= (1ull << 30)) return c->fail("tile too large (slot ids are 30 bits)");
+    const uint32_t nPixels = (uint32_t)np64;
+    RT_HIP(c, hipSetDevice(c->device));
+    if (nPixels == 0) return 0;
+
+    int rc = ensure_state(c, nPixels);
+    if (rc) return rc;
+    float4* fb = (float4*)d_rgba;
+    if (!fb) {
+        const bool fresh = !c->fbBuf.p || c->fbPixels != nPixels;
+        if ((rc = dev_alloc(c, c->fbBuf, (size_t)nPixels * sizeof(float4)))) return rc;
+        if (fresh) RT_HIP(c, hipMemsetAsync(c->fbBuf.p, 0, (size_t)nPixels * sizeof(float4), c->stream));
+        c->fbPixels = nPixels;
+        fb = (float4*)c->fbBuf.p;
+        c->fbValid = true;
+    }
+
+    // ---- per-frame constants (host side of raytrace.comp:547-564)
+    FrameParams fp{};
+    memcpy(fp.camRot, pc->camInfo.cameraRotation, 64);
+    memcpy(fp.camPos, pc->camInfo.pos, 12);
+    fp.planeHeight = pc->camInfo.nearPlane * rt_tan(rt_radians(pc->camInfo.fov * 0.5f)) * 2.f;
+    fp.planeWidth = fp.planeHeight * pc->camInfo.aspectRatio;
+    fp.bottomLeft[0] = -fp.planeWidth / 2.f;
+    fp.bottomLeft[1] = -fp.planeHeight / 2.f;
+    fp.bottomLeft[2] = 0.1f;
+    fp.width = width; fp.height = height; fp.row0 = row0; fp.rowStride = rowStride; fp.nRows = nRows; fp.nPixels = nPixels;
+    uint32_t lol = pc->frameCount;
+    fp.startingSeed = (uint32_t)(rt_random(&lol) * 23892183.f);
+    fp.samples = td.singleRender ? td.sampleLimit : td.raysPerPixel;
+    fp.bounceLimit = td.bounceLimit;
+    fp.progressive = td.progressive;
+    fp.frameCount = pc->frameCount;
+    fp.debug = td.debug;
+    fp.boxCap = td.boxCap;
+    fp.triCap = td.triangleCap;
+    fp.env = pc->environment;
+
+    DevScene sc = c->sc;
+    sc.sphereCount = td.sphereCount;
+    sc.objectCount = td.objectCount;
+    DevScene saved = c->sc;
+    c->sc = sc;
+
+    const uint32_t blocksPix = (nPixels + RT_BLOCK - 1) / RT_BLOCK;
+    DevCounters* dc = (DevCounters*)c->counterBuf.p;
+    uint32_t* counts = c->q.counts;
+
+    hipLaunchKernelGGL(k_raygen, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->ps, c->q, fp);
+    RT_HIP(c, hipGetLastError());
+
+    if (fp.samples > 0) {
+        // counts: [0],[1] active paths of buffer 0/1; [2],[3] rays of buffer 0/1
+        c->hostCounts[0] = nPixels; c->hostCounts[1] = 0; c->hostCounts[2] = nPixels; c->hostCounts[3] = 0;
+        RT_HIP(c, hipMemcpyAsync(counts, c->hostCounts, 16, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+
+        uint32_t ubActive = nPixels;  // active paths never increase
+        int cur = 0;
+        const int checkEvery = 8;
+        for (uint64_t it = 0;; it++) {
+            const int nxt = cur ^ 1;
+            hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, c->stream, counts + nxt, counts + 2 + nxt);
+            TraceArgs ta{c->q.rays[cur], counts + 2 + cur, nullptr, nullptr, dc};
+            uint64_t ubRays = std::min<uint64_t>((uint64_t)ubActive * 3, (uint64_t)nPixels * 3);
+            if ((rc = launch_trace(c, (uint32_t)ubRays, ta))) { c->sc = saved; return rc; }
+            ShadeArgs sa{c->q.active[cur], counts + cur, c->q.active[nxt], c->q.rays[nxt], counts + nxt, counts + 2 + nxt, dc};
+            hipLaunchKernelGGL(k_shade, dim3((ubActive + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, sa, fp);
+            cur = nxt;
+            if ((it + 1) % checkEvery == 0) {
+                RT_HIP(c, hipMemcpyAsync(c->hostCounts, counts + cur, 4, hipMemcpyDeviceToHost, c->stream));
+                RT_HIP(c, hipStreamSynchronize(c->stream));
+                if ((rc = harvest_events(c))) { c->sc = saved; return rc; }
+                ubActive = c->hostCounts[0];
+                if (ubActive == 0) break;
+            }
+            // hard stop: a pixel needs at most samples*(bounceLimit+1) rounds
+            if (it > (uint64_t)fp.samples * ((uint64_t)fp.bounceLimit + 1) + checkEvery) {
+                c->sc = saved;
+                return c->fail("internal: wavefront loop did not drain");
+            }
+        }
+    }
+    hipLaunchKernelGGL(k_resolve, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->ps, fp, fb);
+    RT_HIP(c, hipGetLastError());
+    c->sc = saved;
+    return 0;
+}
+
+int rt_read_rgba_f32(rt_ctx* c, float* out, size_t nFloats) {
+    if (!c || !out) return -1;
+    if (!c->fbValid) return c->fail("no ctx-owned framebuffer: rt_render was never called with d_rgba = NULL");
+    if (nFloats != (size_t)c->fbPixels * 4) return c->fail("rt_read_rgba_f32: size mismatch");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipMemcpyAsync(out, c->fbBuf.p, nFloats * 4, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int rt_read_rgba8_srgb(rt_ctx* c, uint8_t* out, size_t nBytes) {
+    if (!c || !out) return -1;
+    if (!c->fbValid || nBytes != (size_t)c->fbPixels * 4) return c->fail("rt_read_rgba8_srgb: size mismatch");
+    std::vector<float> tmp((size_t)c->fbPixels * 4);
+    int rc = rt_read_rgba_f32(c, tmp.data(), tmp.size());
+    if (rc) return rc;
+    // display encoding only; parity is defined on the fp32 buffer
+    for (size_t i = 0; i < tmp.size(); i++) {
+        float v = tmp[i];
+        if (!(v > 0.f)) v = 0.f;
+        if (v > 1.f) v = 1.f;
+        if ((i & 3) != 3) v = v <= 0.0031308f ? 12.92f * v : 1.055f * rt_pow(v, 1.f / 2.4f) - 0.055f;
+        out[i] = (uint8_t)(v * 255.f + 0.5f);
+    }
+    return 0;
+}
+
+int rt_trace_rays(rt_ctx* c, uint32_t n, const float* origins, const float* dirs, RtHit* hitsOut) {
+    if (!c || !origins || !dirs || !hitsOut) return -1;
+    if (!c->sc.nodes) return c->fail("rt_trace_rays before rt_upload_scene");
+    if (n == 0) return 0;
+    RT_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_state(c, n);
+    if (rc) return rc;
+    std::vector<float> soa((size_t)n * 6);
+    for (uint32_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            soa[(size_t)k * n + i] = origins[(size_t)i * 3 + k];
+            soa[(size_t)(3 + k) * n + i] = dirs[(size_t)i * 3 + k];
+        }
+    for (int k = 0; k < 3; k++) {
+        RT_HIP(c, hipMemcpyAsync(c->ps.rayO[k], &soa[(size_t)k * n], (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        RT_HIP(c, hipMemcpyAsync(c->ps.rayD[k], &soa[(size_t)(3 + k) * n], (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    size_t need = (size_t)n * 8 + (size_t)n * sizeof(RtHit) + 256;
+    if ((rc = dev_alloc(c, c->scratchBuf, need))) return rc;
+    uint32_t* prb = (uint32_t*)c->scratchBuf.p;
+    uint32_t* prt = prb + n;
+    RtHit* dh = (RtHit*)((char*)c->scratchBuf.p + (((size_t)n * 8 + 255) & ~(size_t)255));
+    c->hostCounts[0] = n;
+    RT_HIP(c, hipMemcpyAsync(c->q.counts, c->hostCounts, 4, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->ps.statBox, 0, (size_t)n * 4, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->ps.statTri, 0, (size_t)n * 4, c->stream));
+    TraceArgs ta{nullptr, c->q.counts, prb, prt, (DevCounters*)c->counterBuf.p};
+    if ((rc = launch_trace(c, n, ta))) return rc;
+    hipLaunchKernelGGL(k_hit_details, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, n, prb, prt, dh);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipMemcpyAsync(hitsOut, dh, (size_t)n * sizeof(RtHit), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return harvest_events(c);
+}
+
+int rt_get_counters(rt_ctx* c, RtCounters* out) {
+    if (!c || !out) return -1;
+    RT_HIP(c, hipSetDevice(c->device));
+    DevCounters h;
+    RT_HIP(c, hipMemcpyAsync(&h, c->counterBuf.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    out->boxTests = h.boxTests; out->triTests = h.triTests; out->raysTraced = h.raysTraced; out->raysHit = h.raysHit;
+    out->raysReference = h.raysReference; out->paths = h.paths; out->segments = h.segments;
+    out->traceLaunches = c->traceLaunchesTotal;
+    return 0;
+}
+
+int rt_reset_counters(rt_ctx* c) {
+    if (!c) return -1;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters), c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = harvest_events(c);
+    c->traceMs = 0.0; c->traceLaunches = 0; c->traceLaunchesTotal = 0;
+    return rc;
+}
+
+int rt_set_profiling(rt_ctx* c, int on) {
+    if (!c) return -1;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = harvest_events(c);
+    c->profiling = on != 0;
+    return rc;
+}
+
+int rt_get_trace_time_ms(rt_ctx* c, double* ms, uint64_t* launches) {
+    if (!c) return -1;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = harvest_events(c);
+    if (ms) *ms = c->traceMs;
+    if (launches) *launches = c->traceLaunches;
+    return rc;
+}
+
+int rt_device_selftest(rt_ctx* c, uint32_t* bitsOut) {
+    if (!c || !bitsOut) return -1;
+    RT_HIP(c, hipSetDevice(c->device));
+    const uint32_t n = 4096;
+    std::vector<float> a(n), b(n);
+    uint32_t st = 12345u;
+    for (uint32_t i = 0; i < n; i++) { a[i] = rt_random(&st); b[i] = rt_random(&st) + 1e-3f; }
+    const float kat[7] = {1.0001220703125f, 0.9998779296875f, -1.f, 3.f, 1e-30f, 1e-10f, 2.f};
+    size_t bytes = (size_t)n * 12 + 64 + 64;
+    int rc = dev_alloc(c, c->scratchBuf, bytes);
+    if (rc) return rc;
+    float* da = (float*)c->scratchBuf.p;
+    float* db = da + n;
+    uint32_t* dh = (uint32_t*)(db + n);
+    uint32_t* dbits = dh + n;
+    float* dkat = (float*)(dbits + 8);
+    RT_HIP(c, hipMemcpyAsync(da, a.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(db, b.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(dkat, kat, sizeof(kat), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_selftest, dim3(n / 256), dim3(256), 0, c->stream, da, db, n, dh, dbits, dkat);
+    RT_HIP(c, hipGetLastError());
+    std::vector<uint32_t> h(n);
+    uint32_t bits = 0;
+    RT_HIP(c, hipMemcpyAsync(h.data(), dh, n * 4, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipMemcpyAsync(&bits, dbits, 4, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    uint32_t mismatches = 0;
+    for (uint32_t i = 0; i < n; i++)
+        if (h[i] != selftest_one(a[i], b[i])) mismatches++;
+    // bit 31 set: device and host disagree on some primitive
+    *bitsOut = bits | (mismatches ? 0x80000000u : 0u);
+    if (mismatches) return c->fail("device/host deterministic-math mismatch in " + std::to_string(mismatches) + " of 4096 probes");
+    return 0;
+}
+
+int rt_measure_copy_bandwidth(rt_ctx* c, size_t bytes, int iters, double* gbps) {
+    if (!c || !gbps || iters <= 0) return -1;
+    RT_HIP(c, hipSetDevice(c->device));
+    bytes &= ~(size_t)255;
+    if (bytes < 4096) return c->fail("copy size too small");
+    void *src = nullptr, *dst = nullptr;
+    RT_HIP(c, hipMalloc(&src, bytes));
+    if (hipMalloc(&dst, bytes) != hipSuccess) { (void)hipFree(src); return c->fail("hipMalloc failed"); }
+    (void)hipMemsetAsync(src, 1, bytes, c->stream);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    size_t n = bytes / 16;
+    hipLaunchKernelGGL(k_copy_f4, dim3(256 * 8), dim3(256), 0, c->stream, (const float4*)src, (float4*)dst, n);
+    (void)hipEventRecord(e0, c->stream);
+    for (int i = 0; i < iters; i++)
+        hipLaunchKernelGGL(k_copy_f4, dim3(256 * 8), dim3(256), 0, c->stream, (const float4*)src, (float4*)dst, n);
+    (void)hipEventRecord(e1, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(src); (void)hipFree(dst);
+    if (e != hipSuccess) return c->hip(e, "copy bandwidth");
+    *gbps = (2.0 * (double)bytes * iters) / (ms * 1e-3) / 1e9;  // read + write
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,766 @@
+// rt_kernels.hip.h — device data layout and the wavefront kernels for gfx950.
+//
+// The per-pixel megakernel shaders/raytrace.comp is split into four kernels
+// that exchange work through device queues (indices into SoA path state):
+//
+//   k_raygen   raytrace.comp:539-564   camera ray, RNG seed, path reset
+//   k_trace    raytrace.comp:276-353   closest hit: spheres + per-object BVH
+//              (+ :195-274)            traversal with an LDS-resident stack
+//   k_shade    raytrace.comp:483-537   emission/NEE add, BSDF sample
+//              (+ :356-481)            (diffuse+MIS / mirror / dielectric),
+//                                      Russian roulette, next rays, path
+//                                      regeneration for the next sample
+//   k_resolve  raytrace.comp:566-593   sample mean, progressive blend,
+//                                      NaN->magenta, debug heat maps, store
+//
+// One path slot per pixel; a pixel's samples run one after another in its
+// slot because the shader carries the RNG state serially across the samples
+// of a pixel (:564,571-573). Every arithmetic step uses
+// rt_det_math.h in the same order as the scalar oracle so that pixels and the
+// box/triangle counters are bit-identical, not just within 1e-4.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_amd.h"
+#include "rt_det_math.h"
+
+#define RT_WAVE 64
+#define RT_BLOCK 256
+#define RT_LEAF_BIT 0x80000000u
+#define RT_HIT_NONE 0xffffffffu
+#define RT_HIT_SPHERE 0x80000000u
+
+// ---------------------------------------------------------------- scene in HBM
+// All arrays are read-only during a render.
+//   nodes   : 2 x float4 per BVH node  {min.xyz, index} {max.xyz, triCount}
+//             children of an interior node are adjacent and 64-B aligned, so
+//             one interior visit is one 64-B fetch (the reference re-reads the
+//             popped node and both children: 96 B, raytrace.comp:306,326-327)
+//   triPos  : 3 x float4 per triangle   {v0.xyz, frontOnly} {v1.xyz,-} {v2.xyz,-}
+//             in the reference's (builder-permuted) triangle order; hot
+//   triNrm  : 3 x float4 per triangle   vertex normals; cold, read per hit only
+//   objInv  : 3 x float4 per object     rows of inverse(transformMatrix)[0..2]
+//   objFwd  : 3 x float4 per object     rows of transformMatrix[0..2]
+//   objMeta : uint4 per object          {rootIndex|pairIndex, rootTriCount, materialIndex, -}
+//   mats    : 3 x float4 per material   {albedo, reflectance} {emission, strength} {ior,-,-,-}
+//   spheres : float4 {center, radius} + uint material
+struct DevScene {
+    const float4* nodes;
+    const float4* triPos;
+    const float4* triNrm;
+    const float4* objInv;
+    const float4* objFwd;
+    const uint4* objMeta;
+    const float4* mats;
+    const float4* spheres;
+    const uint32_t* sphereMat;
+    uint32_t sphereCount, objectCount, materialCount, nodeCount, triCount;
+};
+
+// ---------------------------------------------------------------- path state (SoA, one slot per pixel)
+enum { RAY_MAIN = 0, RAY_NEE = 1, RAY_PROBE = 2 };
+
+struct PathState {
+    // current main ray
+    float* rayO[3];
+    float* rayD[3];
+    // the two probe rays of the previous diffuse bounce (shared origin)
+    float* auxO[3];
+    float* auxDL[3];
+    float* auxDC[3];
+    // closest-hit results per ray kind
+    float* hitT[3];
+    uint32_t* hitObj[3];
+    uint32_t* hitTri;  // main ray only
+    // trace() locals (raytrace.comp:484-489)
+    float* att[3];
+    float* total[3];
+    float* direct[3];
+    float* misW;
+    // diffuseBRDF values that wait for the probe results (:446-460)
+    float* pendAlbedo[3];
+    float* pendNDotL;     // max(0, dot(n, lightSample))
+    float* pendCosPdfL;   // cosineHemispherePDF(n, lightSample)
+    float* pendCosPdfC;   // cosineHemispherePDF(n, cosineSample)
+    // main() locals (:562-573)
+    float* accum[3];
+    uint32_t* rng;
+    uint32_t* sample;
+    uint32_t* bounce;   // j; bit 31 = NEE results pending
+    uint32_t* statBox;  // stats[0] of the pixel (main-path traversals only)
+    uint32_t* statTri;  // stats[1]
+};
+
+struct Queues {
+    uint32_t* active[2];  // path slots that have rays in flight
+    uint32_t* rays[2];    // slot*4 + kind
+    uint32_t* counts;     // [0..1] active counts, [2..3] ray counts
+};
+
+struct FrameParams {
+    // camera, precomputed on the host with rt_det_math (raytrace.comp:547-550)
+    float camRot[16];
+    float camPos[3];
+    float planeWidth, planeHeight;
+    float bottomLeft[3];
+    uint32_t width, height, row0, rowStride, nRows, nPixels;
+    uint32_t startingSeed;  // uint(random(frameCount) * 23892183)
+    uint32_t samples, bounceLimit;
+    uint32_t progressive, frameCount;
+    int32_t debug;
+    uint32_t boxCap, triCap;
+    EnvironmentData env;
+};
+
+struct DevCounters {
+    unsigned long long boxTests, triTests, raysTraced, raysHit, raysReference, paths, segments, pad;
+};
+
+// ---------------------------------------------------------------- small helpers
+__device__ __forceinline__ rt_vec3 ld3(float* const p[3], uint32_t i) { return rt_v3(p[0][i], p[1][i], p[2][i]); }
+__device__ __forceinline__ void st3(float* const p[3], uint32_t i, rt_vec3 v) { p[0][i] = v.x; p[1][i] = v.y; p[2][i] = v.z; }
+__device__ __forceinline__ rt_vec3 f4xyz(float4 v) { return rt_v3(v.x, v.y, v.z); }
+
+// (M * vec4(v,0)).xyz and (M * vec4(v,1)).xyz with M given as three rows
+// {m0,m4,m8,m12},{m1,m5,m9,m13},{m2,m6,m10,m14}; same sums as rt_xform_*.
+__device__ __forceinline__ rt_vec3 xform_dir_rows(float4 r0, float4 r1, float4 r2, rt_vec3 v) {
+    return rt_v3((r0.x * v.x + r0.y * v.y) + r0.z * v.z, (r1.x * v.x + r1.y * v.y) + r1.z * v.z,
+                 (r2.x * v.x + r2.y * v.y) + r2.z * v.z);
+}
+__device__ __forceinline__ rt_vec3 xform_point_rows(float4 r0, float4 r1, float4 r2, rt_vec3 v) {
+    return rt_v3(((r0.x * v.x + r0.y * v.y) + r0.z * v.z) + r0.w, ((r1.x * v.x + r1.y * v.y) + r1.z * v.z) + r1.w,
+                 ((r2.x * v.x + r2.y * v.y) + r2.z * v.z) + r2.w);
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, RT_WAVE);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, RT_WAVE);
+    return v;
+}
+
+// ---------------------------------------------------------------- intersections
+struct SphereHit { bool didHit, frontFace; float dst; };
+
+// raytrace.comp:195-224 (distance part)
+__device__ __forceinline__ SphereHit sphere_intersect(float4 s, rt_vec3 ro, rt_vec3 rd) {
+    SphereHit h; h.didHit = false; h.frontFace = false; h.dst = 0.f;
+    rt_vec3 oc = rt_sub(f4xyz(s), ro);
+    float a = rt_dot(rd, rd);
+    float b = rt_dot(oc, rd);
+    float c = rt_dot(oc, oc) - s.w * s.w;
+    float disc = b * b - a * c;
+    if (disc >= 0.f) {
+        float sq = rt_sqrt(disc);
+        float dst = (b - sq) / a;
+        h.frontFace = true;
+        if (dst < 0.f) {
+            dst = (b + sq) / a;
+            h.frontFace = false;
+            if (dst < 0.f) return h;
+        }
+        h.didHit = true;
+        h.dst = dst;
+    }
+    return h;
+}
+
+struct TriHit { bool didHit, frontFace; float dst, u, v, w; };
+
+// raytrace.comp:227-247
+__device__ __forceinline__ TriHit tri_intersect(rt_vec3 ro, rt_vec3 rd, rt_vec3 v0, rt_vec3 v1, rt_vec3 v2, bool frontOnly) {
+    rt_vec3 v1v0 = rt_sub(v1, v0);
+    rt_vec3 v2v0 = rt_sub(v2, v0);
+    rt_vec3 rov0 = rt_sub(ro, v0);
+    rt_vec3 n = rt_cross(v1v0, v2v0);
+    rt_vec3 q = rt_cross(rov0, rd);
+    float d0 = -rt_dot(rd, n);
+    float d = 1.f / d0;
+    TriHit h;
+    h.dst = rt_dot(rov0, n) * d;
+    h.u = rt_dot(v2v0, q) * d;
+    h.v = -rt_dot(v1v0, q) * d;
+    h.w = 1.f - h.u - h.v;
+    h.frontFace = d0 >= 0.00000001f;
+    h.didHit = h.dst >= 0.f && h.u >= 0.f && h.v >= 0.f && h.w >= 0.f && !(!h.frontFace && frontOnly);
+    return h;
+}
+
+// raytrace.comp:263-274
+__device__ __forceinline__ float box_intersect(float4 lo, float4 hi, rt_vec3 ro, rt_vec3 inv) {
+    float ax = (lo.x - ro.x) * inv.x, ay = (lo.y - ro.y) * inv.y, az = (lo.z - ro.z) * inv.z;
+    float bx = (hi.x - ro.x) * inv.x, by = (hi.y - ro.y) * inv.y, bz = (hi.z - ro.z) * inv.z;
+    float tNear = rt_max(rt_max(rt_min(ax, bx), rt_min(ay, by)), rt_min(az, bz));
+    float tFar = rt_min(rt_min(rt_max(ax, bx), rt_max(ay, by)), rt_max(az, bz));
+    bool hit = tFar >= tNear && tFar > 0.f;
+    return hit ? (tNear > 0.f ? tNear : 0.f) : RT_MISS_DST;
+}
+
+// ---------------------------------------------------------------- k_trace
+// One lane per ray. Each lane walks the object list and each object's BVH on
+// its own (no wave-wide object loop), with the same visit order as the shader:
+// far child pushed, near child taken next. The traversal stack lives in LDS,
+// lane-interleaved (entry e of lane l at word e*64+l: conflict-free), and
+// holds only far siblings, so STACK = deepest leaf depth is enough.
+struct TraceArgs {
+    const uint32_t* queue;    // slot*4 + kind, or NULL for identity (slot = gid, kind = MAIN)
+    const uint32_t* count;    // device-side ray count
+    uint32_t* perRayBox;      // optional per-ray stats (rt_trace_rays), indexed by gid
+    uint32_t* perRayTri;
+    DevCounters* counters;
+};
+
+template <int STACK>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, TraceArgs ta) {
+    __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * STACK * RT_WAVE];
+    const uint32_t n = *ta.count;
+    const uint32_t gid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool live = gid < n;
+    if (__ballot(live) == 0ull) return;
+
+    uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * STACK * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
+
+    uint32_t nBox = 0, nTri = 0;
+    uint32_t didHit = 0;
+    uint32_t slot = 0, kind = RAY_MAIN;
+    if (live) {
+        uint32_t id = ta.queue ? ta.queue[gid] : (gid << 2);
+        slot = id >> 2;
+        kind = id & 3u;
+        rt_vec3 ro, rd;
+        if (kind == RAY_MAIN) { ro = ld3(ps.rayO, slot); rd = ld3(ps.rayD, slot); }
+        else { ro = ld3(ps.auxO, slot); rd = (kind == RAY_NEE) ? ld3(ps.auxDL, slot) : ld3(ps.auxDC, slot); }
+
+        float best = RT_MISS_DST;
+        uint32_t bestObj = RT_HIT_NONE, bestTri = 0;
+
+        for (uint32_t i = 0; i < sc.sphereCount; i++) {
+            SphereHit h = sphere_intersect(sc.spheres[i], ro, rd);
+            if (h.didHit && h.dst < best) { best = h.dst; bestObj = RT_HIT_SPHERE | i; }
+        }
+
+        uint32_t obj = 0, sp = 0;
+        uint32_t curIdx = 0, curCnt = 0;
+        bool have = false;
+        rt_vec3 tro = ro, trd = rd, inv = rd;
+        for (;;) {
+            if (!have) {
+                if (sp > 0) {
+                    uint32_t ref = stack[(--sp) * RT_WAVE];
+                    if (ref & RT_LEAF_BIT) {
+                        uint32_t nd = ref & ~RT_LEAF_BIT;
+                        curIdx = __float_as_uint(sc.nodes[2 * nd].w);
+                        curCnt = __float_as_uint(sc.nodes[2 * nd + 1].w);
+                    } else {
+                        curIdx = ref;
+                        curCnt = 0;
+                    }
+                } else {
+                    if (obj >= sc.objectCount) break;
+                    float4 r0 = sc.objInv[3 * obj], r1 = sc.objInv[3 * obj + 1], r2 = sc.objInv[3 * obj + 2];
+                    uint4 meta = sc.objMeta[obj];
+                    trd = xform_dir_rows(r0, r1, r2, rd);
+                    tro = xform_point_rows(r0, r1, r2, ro);
+                    inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
+                    curIdx = meta.x;
+                    curCnt = meta.y;
+                    obj++;
+                }
+                have = true;
+            }
+            if (curCnt != 0) {
+                nTri += curCnt;
+                for (uint32_t j = curIdx; j < curIdx + curCnt; j++) {
+                    float4 a = sc.triPos[3 * j], b = sc.triPos[3 * j + 1], c = sc.triPos[3 * j + 2];
+                    TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
+                    if (h.didHit && h.dst < best) { best = h.dst; bestObj = obj - 1; bestTri = j; }
+                }
+                have = false;
+            } else {
+                const float4* pr = sc.nodes + 2 * (size_t)curIdx;
+                float4 lo1 = pr[0], hi1 = pr[1], lo2 = pr[2], hi2 = pr[3];
+                float d1 = box_intersect(lo1, hi1, tro, inv);
+                float d2 = box_intersect(lo2, hi2, tro, inv);
+                nBox += 2;
+                bool nearA = d1 <= d2;
+                float dNear = nearA ? d1 : d2;
+                float dFar = nearA ? d2 : d1;
+                uint32_t nIdx = __float_as_uint(nearA ? lo1.w : lo2.w), nCnt = __float_as_uint(nearA ? hi1.w : hi2.w);
+                uint32_t fIdx = __float_as_uint(nearA ? lo2.w : lo1.w), fCnt = __float_as_uint(nearA ? hi2.w : hi1.w);
+                if (dFar < best) {
+                    uint32_t farNode = curIdx + (nearA ? 1u : 0u);
+                    stack[sp * RT_WAVE] = fCnt ? (RT_LEAF_BIT | farNode) : fIdx;
+                    sp++;
+                }
+                if (dNear < best) { curIdx = nIdx; curCnt = nCnt; }
+                else have = false;
+            }
+        }
+
+        ps.hitT[kind][slot] = best;
+        ps.hitObj[kind][slot] = bestObj;
+        if (kind == RAY_MAIN) {
+            ps.hitTri[slot] = bestTri;
+            if (ps.statBox) { ps.statBox[slot] += nBox; ps.statTri[slot] += nTri; }
+        }
+        if (ta.perRayBox) { ta.perRayBox[gid] = nBox; ta.perRayTri[gid] = nTri; }
+        didHit = bestObj != RT_HIT_NONE;
+    }
+
+    // one atomic per wave and counter
+    unsigned long long wb = wave_sum_u64(nBox), wt = wave_sum_u64(nTri);
+    uint32_t wr = wave_sum_u32(live ? 1u : 0u), wh = wave_sum_u32(didHit);
+    if (lane_id() == 0) {
+        atomicAdd(&ta.counters->boxTests, wb);
+        atomicAdd(&ta.counters->triTests, wt);
+        atomicAdd(&ta.counters->raysTraced, (unsigned long long)wr);
+        atomicAdd(&ta.counters->raysHit, (unsigned long long)wh);
+    }
+}
+
+// ---------------------------------------------------------------- hit reconstruction
+// The trace kernel stores only (dst, object, triangle). Everything else of the
+// shader's HitInfo is recomputed here with the same operations the traversal
+// used, so the values are the ones calculateIntersections would have stored
+// (raytrace.comp:316-321 for triangles, :217-221 for spheres).
+struct FullHit {
+    rt_vec3 hitPoint, normal;
+    uint32_t materialIndex;
+    bool frontFace;
+};
+
+__device__ __forceinline__ FullHit reconstruct_hit(const DevScene& sc, rt_vec3 ro, rt_vec3 rd, uint32_t obj, uint32_t tri) {
+    FullHit f;
+    if (obj & RT_HIT_SPHERE) {
+        uint32_t i = obj & ~RT_HIT_SPHERE;
+        float4 s = sc.spheres[i];
+        SphereHit h = sphere_intersect(s, ro, rd);
+        f.hitPoint = rt_add(ro, rt_scale(rd, h.dst));
+        f.normal = rt_scale(rt_normalize(rt_sub(f.hitPoint, f4xyz(s))), h.frontFace ? 1.f : -1.f);
+        f.materialIndex = sc.sphereMat[i];
+        f.frontFace = h.frontFace;
+        return f;
+    }
+    float4 i0 = sc.objInv[3 * obj], i1 = sc.objInv[3 * obj + 1], i2 = sc.objInv[3 * obj + 2];
+    float4 m0 = sc.objFwd[3 * obj], m1 = sc.objFwd[3 * obj + 1], m2 = sc.objFwd[3 * obj + 2];
+    rt_vec3 trd = xform_dir_rows(i0, i1, i2, rd);
+    rt_vec3 tro = xform_point_rows(i0, i1, i2, ro);
+    float4 a = sc.triPos[3 * (size_t)tri], b = sc.triPos[3 * (size_t)tri + 1], c = sc.triPos[3 * (size_t)tri + 2];
+    TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
+    rt_vec3 n0 = f4xyz(sc.triNrm[3 * (size_t)tri]), n1 = f4xyz(sc.triNrm[3 * (size_t)tri + 1]), n2 = f4xyz(sc.triNrm[3 * (size_t)tri + 2]);
+    rt_vec3 ni = rt_add(rt_add(rt_scale(n0, h.w), rt_scale(n1, h.u)), rt_scale(n2, h.v));
+    ni = rt_scale(ni, h.frontFace ? 1.f : -1.f);
+    rt_vec3 op = rt_add(tro, rt_scale(trd, h.dst));
+    f.normal = rt_normalize(xform_dir_rows(m0, m1, m2, ni));
+    f.hitPoint = xform_point_rows(m0, m1, m2, op);
+    f.materialIndex = sc.objMeta[obj].z;
+    f.frontFace = h.frontFace;
+    return f;
+}
+
+__device__ __forceinline__ uint32_t hit_material(const DevScene& sc, uint32_t obj) {
+    return (obj & RT_HIT_SPHERE) ? sc.sphereMat[obj & ~RT_HIT_SPHERE] : sc.objMeta[obj].z;
+}
+
+// ---------------------------------------------------------------- shading pieces
+// raytrace.comp:177-181
+__device__ __forceinline__ float schlick(float cosine, float ri) {
+    float r0 = (1.f - ri) / (1.f + ri);
+    r0 = r0 * r0;
+    return r0 + (1.f - r0) * rt_pow(1.f - cosine, 5.f);
+}
+
+// raytrace.comp:356-365
+__device__ __forceinline__ rt_vec3 environment_light(const EnvironmentData& env, rt_vec3 d) {
+    if (!(env.lightDir[3] == 1.f)) return rt_v3(0.f, 0.f, 0.f);
+    float skyT = rt_pow(rt_smoothstep(0.f, 0.4f, -d.y), 0.35f);
+    rt_vec3 sky = rt_v3(rt_mix(env.horizonColor[0], env.zenithColor[0], skyT), rt_mix(env.horizonColor[1], env.zenithColor[1], skyT),
+                        rt_mix(env.horizonColor[2], env.zenithColor[2], skyT));
+    rt_vec3 negL = rt_v3(-env.lightDir[0], -env.lightDir[1], -env.lightDir[2]);
+    float sun = rt_pow(rt_max(0.f, rt_dot(d, negL)), env.horizonColor[3]) * env.zenithColor[3];
+    float g2s = rt_smoothstep(-0.01f, 0.f, -d.y);
+    float sunMask = g2s >= 1.f ? 1.f : 0.f;
+    float add = sun * sunMask;
+    return rt_v3(rt_mix(env.groundColor[0], sky.x, g2s) + add, rt_mix(env.groundColor[1], sky.y, g2s) + add,
+                 rt_mix(env.groundColor[2], sky.z, g2s) + add);
+}
+
+// raytrace.comp:389-403 given the probe ray's closest hit
+__device__ __forceinline__ float light_sample_pdf(const DevScene& sc, float t, uint32_t obj, rt_vec3 dir) {
+    if (obj == RT_HIT_NONE) return 0.f;
+    uint32_t m = hit_material(sc, obj);
+    if (sc.mats[3 * m + 1].w == 0.f) return 0.f;
+    float sq = t * t;
+    float cosTheta = rt_dot(rt_v3(0.f, -1.f, 0.f), dir);
+    return sq / (cosTheta * 0.4444444f);
+}
+
+// raytrace.comp:547-556 for one pixel
+__device__ __forceinline__ rt_vec3 primary_dir(const FrameParams& fp, uint32_t gx, uint32_t gy) {
+    float u = (float)gx / (float)fp.width;
+    float v = (float)gy / (float)fp.height;
+    rt_vec3 point = rt_add(rt_v3(fp.bottomLeft[0], fp.bottomLeft[1], fp.bottomLeft[2]),
+                           rt_v3(fp.planeWidth * u, fp.planeHeight * v, 0.f));
+    rt_vec3 dir = rt_normalize(point);
+    return rt_xform_point(fp.camRot, dir);
+}
+
+__device__ __forceinline__ void slot_to_pixel(const FrameParams& fp, uint32_t slot, uint32_t& gx, uint32_t& gy) {
+    uint32_t k = slot / fp.width;
+    gx = slot - k * fp.width;
+    gy = fp.row0 + k * fp.rowStride;
+}
+
+// ---------------------------------------------------------------- k_raygen
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(PathState ps, Queues q, FrameParams fp) {
+    uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (slot >= fp.nPixels) return;
+    uint32_t gx, gy;
+    slot_to_pixel(fp, slot, gx, gy);
+    st3(ps.rayO, slot, rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]));
+    st3(ps.rayD, slot, primary_dir(fp, gx, gy));
+    ps.rng[slot] = gy * fp.width + gx + fp.startingSeed;
+    st3(ps.att, slot, rt_v3(1.f, 1.f, 1.f));
+    st3(ps.total, slot, rt_v3(0.f, 0.f, 0.f));
+    st3(ps.direct, slot, rt_v3(0.f, 0.f, 0.f));
+    ps.misW[slot] = 1.f;
+    st3(ps.accum, slot, rt_v3(0.f, 0.f, 0.f));
+    ps.sample[slot] = 0;
+    ps.bounce[slot] = 0;
+    ps.statBox[slot] = 0;
+    ps.statTri[slot] = 0;
+    q.active[0][slot] = slot;
+    q.rays[0][slot] = slot << 2;
+}
+
+// ---------------------------------------------------------------- k_shade
+struct ShadeArgs {
+    const uint32_t* inActive;
+    const uint32_t* inCount;
+    uint32_t* outActive;
+    uint32_t* outRays;
+    uint32_t* outActiveCount;
+    uint32_t* outRayCount;
+    DevCounters* counters;
+};
+
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, ShadeArgs sa, FrameParams fp) {
+    const uint32_t n = *sa.inCount;
+    const uint32_t gid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool live = gid < n;
+    if (__ballot(live) == 0ull) return;
+
+    bool alive = false;    // path (or its successor sample) has a main ray for the next round
+    bool wantAux = false;  // and two probe rays
+    uint32_t slot = 0;
+    uint32_t refRays = 0, nPaths = 0;
+
+    if (live) {
+        slot = sa.inActive[gid];
+        rt_vec3 ro = ld3(ps.rayO, slot), rd = ld3(ps.rayD, slot);
+        rt_vec3 att = ld3(ps.att, slot), total = ld3(ps.total, slot), direct = ld3(ps.direct, slot);
+        float misW = ps.misW[slot];
+        uint32_t state = ps.rng[slot];
+        uint32_t jraw = ps.bounce[slot];
+        uint32_t j = jraw & 0x7fffffffu;
+        const bool pending = (jraw >> 31) != 0u;
+
+        const float t = ps.hitT[RAY_MAIN][slot];
+        const uint32_t obj = ps.hitObj[RAY_MAIN][slot];
+        refRays = 1;  // this segment's calculateIntersections (raytrace.comp:496)
+
+        bool done = false;       // this sample's trace() returned
+        bool zeroed = false;     // ... through the NaN/negative early-out (:505)
+
+        if (obj != RT_HIT_NONE) {
+            if (pending) {
+                // finish diffuseBRDF of the previous bounce (:443-460); its three
+                // scene queries were the NEE ray (once for :443 and :447) and the
+                // cosine probe (:453)
+                float tL = ps.hitT[RAY_NEE][slot], tC = ps.hitT[RAY_PROBE][slot];
+                uint32_t oL = ps.hitObj[RAY_NEE][slot], oC = ps.hitObj[RAY_PROBE][slot];
+                rt_vec3 dL = ld3(ps.auxDL, slot), dC = ld3(ps.auxDC, slot);
+                uint32_t lm = (oL == RT_HIT_NONE) ? 0u : hit_material(sc, oL);
+                float4 lmE = sc.mats[3 * lm + 1];
+                float realLightPDF = light_sample_pdf(sc, tL, oL, dL);
+                float cosinePDF = ps.pendCosPdfL[slot];
+                float misWeight1 = realLightPDF * realLightPDF / (realLightPDF * realLightPDF + cosinePDF * cosinePDF);
+                if (rt_isnan(misWeight1)) misWeight1 = 0.f;
+                float lightPDF = light_sample_pdf(sc, tC, oC, dC);
+                float realCosinePDF = ps.pendCosPdfC[slot];
+                float misWeight2 = realCosinePDF * realCosinePDF / (lightPDF * lightPDF + realCosinePDF * realCosinePDF);
+                if (rt_isnan(misWeight2)) misWeight2 = 0.f;
+                rt_vec3 albedo = ld3(ps.pendAlbedo, slot);
+                rt_vec3 dl = rt_scale(rt_v3(lmE.x, lmE.y, lmE.z), lmE.w);
+                float k = (realLightPDF == 0.f) ? 0.f : misWeight1 / realLightPDF;
+                rt_vec3 f = rt_scale(rt_scale(rt_scale(albedo, RT_INV_PI), ps.pendNDotL[slot]), k);
+                direct = rt_mul(dl, f);
+                misW = misWeight2;
+            }
+
+            FullHit hit = reconstruct_hit(sc, ro, rd, obj, ps.hitTri[slot]);
+            float4 mA = sc.mats[3 * hit.materialIndex], mE = sc.mats[3 * hit.materialIndex + 1], mI = sc.mats[3 * hit.materialIndex + 2];
+
+            // 0-1 NEE (:501-505)
+            rt_vec3 emission = rt_scale(rt_v3(mE.x, mE.y, mE.z), mE.w);
+            emission = rt_v3(emission.x / misW, emission.y / misW, emission.z / misW);
+            rt_vec3 finalLight = direct.x == -1.f ? emission : direct;
+            total = rt_add(total, rt_mul(finalLight, att));
+            if (j == 0) total = rt_add(total, emission);
+            if (rt_isnan(total.x) || rt_isnan(total.y) || rt_isnan(total.z) || total.x < 0.f || total.y < 0.f || total.z < 0.f) {
+                done = true;
+                zeroed = true;
+            } else {
+                rt_vec3 sampledDir, radiance;
+                float originSign = 1.f;
+                bool diffuse = false;
+                if (mA.w != 0.f) {  // reflectance != 0: mirror (:466-469)
+                    sampledDir = rt_reflect(rd, hit.normal);
+                    radiance = rt_v3(1.f, 1.f, 1.f);
+                    direct = rt_v3(-1.f, -1.f, -1.f);
+                    misW = 1.f;
+                } else if (mI.x != -1.f) {  // dielectric (:471-481)
+                    float ior = !hit.frontFace ? mI.x : 1.f / mI.x;
+                    float cosine = rt_dot(rt_neg(rd), hit.normal);
+                    float sine = rt_sqrt(1.f - cosine * cosine);
+                    bool solution = (ior * sine) > 1.f;
+                    if (!solution) solution = schlick(cosine, ior) > rt_random(&state);
+                    sampledDir = solution ? rt_reflect(rd, hit.normal) : rt_refract(rd, hit.normal, ior);
+                    originSign = solution ? 1.f : rt_sign(rt_dot(hit.normal, rd));
+                    radiance = rt_v3(1.f, 1.f, 1.f);
+                    direct = rt_v3(-1.f, -1.f, -1.f);
+                    misW = 1.f;
+                } else {  // diffuse + NEE/MIS (:430-464), first half
+                    diffuse = true;
+                    refRays += 3;
+                    rt_vec3 albedo = rt_v3(mA.x, mA.y, mA.z);
+                    rt_vec3 origin = rt_add(hit.hitPoint, rt_scale(hit.normal, 0.01f));
+                    // lightSampleDir (:368-387)
+                    float lx = rt_random(&state);
+                    float lz = rt_random(&state);
+                    rt_vec3 lp = rt_v3(rt_mix(-0.33333f, 0.33333f, lx), -1.5f, rt_mix(-0.33333f, 0.33333f, lz));
+                    rt_vec3 lightSample = rt_normalize(rt_sub(lp, origin));
+                    // cosineHemisphereDir (:405-424)
+                    float r1 = rt_random(&state);
+                    float r2 = rt_random(&state);
+                    float phi = (2.f * RT_PI) * r1;
+                    float sqrtR2 = rt_sqrt(r2);
+                    float sn, cs;
+                    rt_sincos(phi, &sn, &cs);
+                    float x = cs * sqrtR2, y = sn * sqrtR2, z = rt_sqrt(1.f - r2);
+                    rt_vec3 axis = rt_abs(rt_dot(hit.normal, rt_v3(1.f, 0.f, 0.f))) < 1.f ? rt_v3(1.f, 0.f, 0.f) : rt_v3(0.f, 0.f, 1.f);
+                    rt_vec3 tt = rt_normalize(rt_cross(hit.normal, axis));
+                    rt_vec3 bb = rt_cross(hit.normal, tt);
+                    rt_vec3 cosineSample = rt_add(rt_add(rt_scale(tt, x), rt_scale(bb, y)), rt_scale(hit.normal, z));
+
+                    float realCosinePDF = rt_max(0.f, rt_dot(cosineSample, hit.normal) * RT_INV_PI);
+                    float nDotC = rt_dot(hit.normal, cosineSample);
+                    radiance = rt_scale(rt_scale(albedo, RT_INV_PI), nDotC);
+                    radiance = rt_v3(radiance.x / realCosinePDF, radiance.y / realCosinePDF, radiance.z / realCosinePDF);
+                    sampledDir = cosineSample;
+
+                    st3(ps.auxO, slot, origin);
+                    st3(ps.auxDL, slot, lightSample);
+                    st3(ps.auxDC, slot, cosineSample);
+                    st3(ps.pendAlbedo, slot, albedo);
+                    ps.pendNDotL[slot] = rt_max(0.f, rt_dot(hit.normal, lightSample));
+                    ps.pendCosPdfL[slot] = rt_max(0.f, rt_dot(lightSample, hit.normal) * RT_INV_PI);
+                    ps.pendCosPdfC[slot] = realCosinePDF;
+                }
+                att = rt_mul(att, radiance);
+
+                // russian roulette (:520-524)
+                float rrProb = rt_max(rt_max(att.x, att.y), att.z);
+                rrProb = rt_min(rrProb, 0.95f);
+                rrProb = j <= 5 ? 1.f : rrProb;
+                if (rt_random(&state) > rrProb) {
+                    done = true;
+                } else {
+                    float invP = 1.f / rrProb;
+                    att = rt_scale(att, invP);
+                    ro = rt_add(hit.hitPoint, rt_scale(rt_scale(hit.normal, originSign), 0.00001f));
+                    rd = sampledDir;
+                    j++;
+                    if (j > fp.bounceLimit) done = true;  // the for loop ends (:495)
+                    else wantAux = diffuse;
+                }
+            }
+        } else {
+            // miss (:532-533)
+            total = rt_add(total, rt_mul(att, environment_light(fp.env, rd)));
+            done = true;
+        }
+
+        if (done) {
+            nPaths = 1;
+            rt_vec3 acc = ld3(ps.accum, slot);
+            if (zeroed) total = rt_v3(0.f, 0.f, 0.f);
+            acc = rt_add(acc, total);
+            st3(ps.accum, slot, acc);
+            uint32_t s = ps.sample[slot] + 1;
+            ps.sample[slot] = s;
+            if (s < fp.samples) {
+                // next sample of this pixel: same primary ray, RNG state runs on (:571-573)
+                uint32_t gx, gy;
+                slot_to_pixel(fp, slot, gx, gy);
+                ro = rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]);
+                rd = primary_dir(fp, gx, gy);
+                att = rt_v3(1.f, 1.f, 1.f);
+                total = rt_v3(0.f, 0.f, 0.f);
+                direct = rt_v3(0.f, 0.f, 0.f);
+                misW = 1.f;
+                j = 0;
+                alive = true;
+                wantAux = false;
+            }
+        } else {
+            alive = true;
+        }
+
+        if (alive) {
+            st3(ps.rayO, slot, ro);
+            st3(ps.rayD, slot, rd);
+            st3(ps.att, slot, att);
+            st3(ps.total, slot, total);
+            st3(ps.direct, slot, direct);
+            ps.misW[slot] = misW;
+            ps.bounce[slot] = j | (wantAux ? 0x80000000u : 0u);
+        }
+        ps.rng[slot] = state;
+    }
+
+    // wave-level compaction: one atomic per wave and queue, ranks from ballots
+    const unsigned long long mAlive = __ballot(alive);
+    const unsigned long long mAux = __ballot(alive && wantAux);
+    const uint32_t nAlive = __popcll(mAlive), nAux = __popcll(mAux);
+    uint32_t baseA = 0, baseR = 0;
+    if (lane_id() == 0 && nAlive) {
+        baseA = atomicAdd(sa.outActiveCount, nAlive);
+        baseR = atomicAdd(sa.outRayCount, nAlive + 2u * nAux);
+    }
+    baseA = __shfl(baseA, 0, RT_WAVE);
+    baseR = __shfl(baseR, 0, RT_WAVE);
+    if (alive) {
+        uint32_t rk = lanes_below(mAlive);
+        sa.outActive[baseA + rk] = slot;
+        // main rays first, then the NEE rays, then the cosine probes of this wave
+        sa.outRays[baseR + rk] = (slot << 2) | RAY_MAIN;
+        if (wantAux) {
+            uint32_t ra = lanes_below(mAux);
+            sa.outRays[baseR + nAlive + ra] = (slot << 2) | RAY_NEE;
+            sa.outRays[baseR + nAlive + nAux + ra] = (slot << 2) | RAY_PROBE;
+        }
+    }
+
+    uint32_t wRef = wave_sum_u32(refRays), wPaths = wave_sum_u32(nPaths), wSeg = wave_sum_u32(live ? 1u : 0u);
+    if (lane_id() == 0) {
+        atomicAdd(&sa.counters->raysReference, (unsigned long long)wRef);
+        atomicAdd(&sa.counters->paths, (unsigned long long)wPaths);
+        atomicAdd(&sa.counters->segments, (unsigned long long)wSeg);
+    }
+}
+
+// ---------------------------------------------------------------- k_resolve
+// raytrace.comp:574-593. `rgba` holds the previous frame when progressive
+// (kept in fp32 instead of the reference's 8-bit image).
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathState ps, FrameParams fp, float4* rgba) {
+    uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (slot >= fp.nPixels) return;
+    rt_vec3 out = ld3(ps.accum, slot);
+    float fs = (float)fp.samples;
+    out = rt_v3(out.x / fs, out.y / fs, out.z / fs);
+    float weight = 1.f / ((float)fp.frameCount + 1.f);
+    float4 oldc = rgba[slot];
+    rt_vec3 blended = rt_add(rt_scale(rt_v3(oldc.x, oldc.y, oldc.z), 1.f - weight), rt_scale(out, weight));
+    rt_vec3 fin = fp.progressive ? blended : out;
+    if (rt_isnan(fin.x) || rt_isnan(fin.y) || rt_isnan(fin.z) || rt_isinf(fin.x) || rt_isinf(fin.y) || rt_isinf(fin.z))
+        fin = rt_v3(1.f, 0.f, 1.f);
+    float s0 = (float)ps.statBox[slot], s1 = (float)ps.statTri[slot];
+    float boxCap = (float)fp.boxCap, triCap = (float)fp.triCap;
+    if (fp.debug == 0) {
+        fin = s0 > boxCap ? rt_v3(1.f, 0.f, 0.f) : rt_v3(s0 / boxCap, s0 / boxCap, s0 / boxCap);
+    } else if (fp.debug == 1) {
+        fin = s1 > triCap ? rt_v3(1.f, 0.f, 0.f) : rt_v3(s1 / triCap, s1 / triCap, s1 / triCap);
+    } else if (fp.debug == 2) {
+        fin = rt_v3(s0 / boxCap, 0.f, s1 / triCap);
+    }
+    rgba[slot] = make_float4(fin.x, fin.y, fin.z, 1.f);
+}
+
+// ---------------------------------------------------------------- rt_trace_rays support
+__global__ __launch_bounds__(RT_BLOCK) void k_hit_details(DevScene sc, PathState ps, uint32_t n, const uint32_t* perRayBox,
+                                                          const uint32_t* perRayTri, RtHit* out) {
+    uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    RtHit h;
+    memset(&h, 0, sizeof(h));
+    h.dst = ps.hitT[RAY_MAIN][i];
+    uint32_t obj = ps.hitObj[RAY_MAIN][i];
+    h.boxTests = perRayBox[i];
+    h.triTests = perRayTri[i];
+    if (obj != RT_HIT_NONE) {
+        FullHit f = reconstruct_hit(sc, ld3(ps.rayO, i), ld3(ps.rayD, i), obj, ps.hitTri[i]);
+        h.didHit = 1;
+        h.isSphere = (obj & RT_HIT_SPHERE) ? 1u : 0u;
+        h.objectHitIndex = obj & ~RT_HIT_SPHERE;
+        h.triHitIndex = h.isSphere ? 0u : ps.hitTri[i];
+        h.materialIndex = f.materialIndex;
+        h.frontFace = f.frontFace;
+        h.hitPoint[0] = f.hitPoint.x; h.hitPoint[1] = f.hitPoint.y; h.hitPoint[2] = f.hitPoint.z;
+        h.normal[0] = f.normal.x; h.normal[1] = f.normal.y; h.normal[2] = f.normal.z;
+    }
+    out[i] = h;
+}
+
+// ---------------------------------------------------------------- misc kernels
+__global__ void k_zero_counts(uint32_t* a, uint32_t* b) {
+    if (threadIdx.x == 0) { *a = 0; *b = 0; }
+}
+
+// Hash of the deterministic-math primitives over a fixed input table; the
+// host computes the same hash with the same header (rt_device_selftest).
+__device__ __host__ inline uint32_t selftest_mix(uint32_t h, float v) {
+    h ^= rt_f2u(v);
+    h *= 16777619u;
+    return h;
+}
+__device__ __host__ inline uint32_t selftest_one(float a, float b) {
+    uint32_t h = 2166136261u;
+    float s, c;
+    rt_sincos(a * 6.2831855f, &s, &c);
+    h = selftest_mix(h, s); h = selftest_mix(h, c);
+    h = selftest_mix(h, a / b); h = selftest_mix(h, 1.f / (b + 0.25f));
+    h = selftest_mix(h, rt_sqrt(a)); h = selftest_mix(h, rt_pow(a, 5.f)); h = selftest_mix(h, rt_pow(a, 0.35f));
+    h = selftest_mix(h, rt_log2(b + 1e-3f)); h = selftest_mix(h, rt_exp2(a * 20.f - 10.f));
+    rt_vec3 v = rt_normalize(rt_v3(a - 0.5f, b - 0.5f, a * b + 0.1f));
+    h = selftest_mix(h, v.x); h = selftest_mix(h, v.y); h = selftest_mix(h, v.z);
+    h = selftest_mix(h, rt_dot(v, rt_v3(b, a, 0.3f)));
+    rt_vec3 r = rt_refract(v, rt_normalize(rt_v3(0.1f, 1.f, b)), 0.5f + a);
+    h = selftest_mix(h, r.x); h = selftest_mix(h, r.y); h = selftest_mix(h, r.z);
+    h = selftest_mix(h, rt_smoothstep(0.f, 0.4f, a)); h = selftest_mix(h, rt_min(a, b)); h = selftest_mix(h, rt_max(a, b));
+    h = selftest_mix(h, a * b + b);  // would differ if contracted to an fma
+    uint32_t st = rt_f2u(a) ^ (rt_f2u(b) * 7u);
+    h = selftest_mix(h, rt_random(&st));
+    return h;
+}
+__global__ void k_selftest(const float* a, const float* b, uint32_t n, uint32_t* hashOut, uint32_t* bitsOut, const float* kat) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) hashOut[i] = selftest_one(a[i], b[i]);
+    if (i == 0) *bitsOut = rt_selftest_bits(kat);
+}
+
+__global__ void k_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[i];
+}

@@ -1,0 +1,327 @@
+"""Host-side mirror of the reference engine's path-tracing surface.
+
+`Scene` keeps the reference's scene vectors and builders (VulkanEngine::
+read_obj / read_mtl / cornell_box / prepare_storage_buffers,
+src/vk_engine.cpp:638-758, 800-1167) behind the C ABI's scene half.
+`Renderer` is the device half: `upload_scene` = the copy_buffer calls
+(src/vk_engine.cpp:753-757), `update_*` = update_buffer (:1446-1475),
+`run_compute` = run_compute (:1623-1676) with the same frame semantics
+(`totalSamples < sampleLimit`, single render = one dispatch of sampleLimit spp,
+otherwise raysPerPixel spp per dispatch and frameCount advancing only when
+progressive, :1782,1812-1814).
+
+Everything numeric happens in librt_amd.so; this file only moves pointers.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import (BVHNode, PushConstants, RayMaterial, RenderObject, RtCounters, RtHit, RtPlacement,
+                    RtSceneArrays, Sphere, Triangle, TrianglePoint)
+
+ASSET_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def placement(position=(0, 0, 0), rotation=(0, 0, 0), scale=(1, 1, 1), samplerIndex=0, frontOnly=False):
+    """ImGuiObject's placement fields (src/vk_engine.h:125-132)."""
+    p = RtPlacement()
+    _capi.lib().rt_placement_default(C.byref(p))
+    if np.isscalar(scale):
+        scale = (scale,) * 3
+    p.position[:] = [float(x) for x in position]
+    p.rotation[:] = [float(x) for x in rotation]
+    p.scale[:] = [float(x) for x in scale]
+    p.samplerIndex = int(samplerIndex)
+    p.frontOnly = 1 if frontOnly else 0
+    return p
+
+
+def default_material(**kw):
+    m = RayMaterial()
+    _capi.lib().rt_material_default(C.byref(m))
+    for k, v in kw.items():
+        if k in ("albedo", "emissionColor"):
+            getattr(m, k)[:] = [float(x) for x in v]
+        else:
+            setattr(m, k, v)
+    return m
+
+
+def push_constants(width, height, **params):
+    """PushConstants with the reference's defaults (src/vk_engine.h:145-171,325).
+    Keyword names are the reference's field names; `cameraAngles` (degrees)
+    recomputes cameraRotation as run_compute does."""
+    pc = PushConstants()
+    l = _capi.lib()
+    l.rt_push_constants_default(C.byref(pc), width, height)
+    for k, v in params.items():
+        if k == "cameraAngles":
+            ang = (C.c_float * 3)(*[float(x) for x in v])
+            l.rt_camera_rotation(ang, pc.camInfo.cameraRotation)
+        elif k in ("pos",):
+            pc.camInfo.pos[:] = [float(x) for x in v]
+        elif k in ("nearPlane", "aspectRatio", "fov"):
+            setattr(pc.camInfo, k, float(v))
+        elif k in ("horizonColor", "zenithColor", "groundColor", "lightDir"):
+            getattr(pc.environment, k)[:] = [float(x) for x in v]
+        elif k == "environmentOn":
+            pc.environment.lightDir[3] = 1.0 if v else 0.0
+        elif k == "frameCount":
+            pc.frameCount = int(v)
+        elif hasattr(pc.rayTraceParams, k):
+            setattr(pc.rayTraceParams, k, int(v))
+        else:
+            raise KeyError(k)
+    return pc
+
+
+class Scene:
+    """The reference's CPU-side scene: spheres, rayMaterials, triPoints,
+    triangles, objects, bvhNodes (src/vk_engine.h:270-283)."""
+
+    def __init__(self):
+        self._l = _capi.lib()
+        h = C.c_void_p()
+        if self._l.rt_scene_create(C.byref(h)) != 0:
+            raise RtError("rt_scene_create failed")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._l.rt_scene_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise RtError(f"{what}: {self._l.rt_scene_last_error(self._h).decode()}")
+        return rc
+
+    # -- builders ---------------------------------------------------------
+    def add_material(self, m):
+        return self._check(self._l.rt_scene_add_material(self._h, C.byref(m)), "add_material")
+
+    def set_sphere(self, i, position, radius, materialIndex):
+        pos = (C.c_float * 3)(*[float(x) for x in position])
+        self._check(self._l.rt_scene_set_sphere(self._h, i, pos, float(radius), int(materialIndex)), "set_sphere")
+
+    def read_obj(self, filePath, imGuiObj=None, material=0):
+        p = imGuiObj if imGuiObj is not None else placement()
+        return self._check(self._l.rt_scene_read_obj(self._h, os.fsencode(filePath), C.byref(p), int(material)),
+                           "read_obj")
+
+    def read_mtl(self, filePath):
+        return self._check(self._l.rt_scene_read_mtl(self._h, os.fsencode(filePath)), "read_mtl")
+
+    def add_mesh(self, key, positions, normals, imGuiObj=None, material=0, uvs=None):
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 9)
+        nrm = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 9)
+        assert pos.shape == nrm.shape
+        fp = C.POINTER(C.c_float)
+        uvp = None
+        if uvs is not None:
+            uvs = np.ascontiguousarray(uvs, dtype=np.float32).reshape(-1, 6)
+            uvp = uvs.ctypes.data_as(fp)
+        p = imGuiObj if imGuiObj is not None else placement()
+        return self._check(self._l.rt_scene_add_mesh(self._h, key.encode(), pos.ctypes.data_as(fp),
+                                                     nrm.ctypes.data_as(fp), uvp, pos.shape[0], C.byref(p),
+                                                     int(material)), "add_mesh")
+
+    def cornell_box(self, assetDir=ASSET_DIR):
+        self._check(self._l.rt_scene_cornell_box(self._h, os.fsencode(assetDir)), "cornell_box")
+
+    def prepare_storage_buffers(self, assetDir=ASSET_DIR):
+        self._check(self._l.rt_scene_prepare_default(self._h, os.fsencode(assetDir)), "prepare_storage_buffers")
+
+    def find_material(self, key):
+        return self._l.rt_scene_find_material(self._h, key.encode())
+
+    def last_bvh_stats(self):
+        v = [C.c_uint32() for _ in range(4)]
+        self._l.rt_scene_last_bvh_stats(self._h, *[C.byref(x) for x in v])
+        return dict(zip(("nodeCount", "maxDepth", "minDepth", "maxTri"), [x.value for x in v]))
+
+    # -- views ------------------------------------------------------------
+    def arrays(self):
+        a = RtSceneArrays()
+        self._check(self._l.rt_scene_get_arrays(self._h, C.byref(a)), "get_arrays")
+        return a
+
+    def _view(self, ptr, n, ctype):
+        if n == 0:
+            return np.zeros((0,), dtype=np.uint8)
+        buf = (ctype * n).from_address(C.addressof(ptr.contents))
+        return np.frombuffer(buf, dtype=np.uint8).reshape(n, C.sizeof(ctype))
+
+    def numpy(self):
+        """Raw byte views (copied) of the six scene arrays, for tests."""
+        a = self.arrays()
+        return {
+            "spheres": self._view(a.spheres, a.sphereCount, Sphere).copy(),
+            "materials": self._view(a.materials, a.materialCount, RayMaterial).copy(),
+            "triPoints": self._view(a.triPoints, a.triPointCount, TrianglePoint).copy(),
+            "triangles": self._view(a.triangles, a.triangleCount, Triangle).copy(),
+            "objects": self._view(a.objects, a.objectCount, RenderObject).copy(),
+            "bvhNodes": self._view(a.bvhNodes, a.bvhNodeCount, BVHNode).copy(),
+        }
+
+    def counts(self):
+        a = self.arrays()
+        return dict(spheres=a.sphereCount, materials=a.materialCount, triPoints=a.triPointCount,
+                    triangles=a.triangleCount, objects=a.objectCount, bvhNodes=a.bvhNodeCount)
+
+
+class Renderer:
+    """One MI355X: device buffers + the wavefront pipeline (rt_ctx)."""
+
+    def __init__(self, device=0):
+        self._l = _capi.lib()
+        h = C.c_void_p()
+        rc = self._l.rt_create(int(device), C.byref(h))
+        if rc != 0:
+            raise RtError(f"rt_create(device={device}) failed with {rc}: no usable HIP device "
+                          "(this path has no CPU fallback)")
+        self._h = h
+        self.device = device
+        self.totalSamples = 0
+        self._frameNumber = 0
+        self._scene = None
+        self._shape = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.rt_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RtError(f"{what} failed ({rc}): {self._l.rt_last_error(self._h).decode()}")
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._l.rt_set_stream(self._h, C.c_void_p(hip_stream_ptr)), "rt_set_stream")
+
+    def upload_scene(self, scene):
+        a = scene.arrays()
+        self._check(self._l.rt_upload_scene(self._h, C.byref(a)), "rt_upload_scene")
+        self._scene = scene
+        self._counts = scene.counts()
+
+    def update_materials(self, scene):
+        a = scene.arrays()
+        self._check(self._l.rt_update_materials(self._h, a.materials, a.materialCount), "rt_update_materials")
+
+    def update_spheres(self, scene):
+        a = scene.arrays()
+        self._check(self._l.rt_update_spheres(self._h, a.spheres, a.sphereCount), "rt_update_spheres")
+
+    def update_objects(self, scene):
+        a = scene.arrays()
+        self._check(self._l.rt_update_objects(self._h, a.objects, a.objectCount), "rt_update_objects")
+
+    def fill_counts(self, pc):
+        """rayTracerParams.sphereCount/objectCount as run_compute sets them (:1655-1656)."""
+        pc.rayTraceParams.sphereCount = self._counts["spheres"]
+        pc.rayTraceParams.objectCount = self._counts["objects"]
+        return pc
+
+    def render(self, pc, width, height, row0=0, rowStride=1, nRows=None, out_ptr=None, sync=True):
+        """One dispatch. Returns an (nRows, width, 4) float32 array unless the
+        caller supplied a device pointer."""
+        if nRows is None:
+            nRows = (height - row0 + rowStride - 1) // rowStride
+        self.fill_counts(pc)
+        self._check(self._l.rt_render(self._h, C.byref(pc), width, height, row0, rowStride, nRows,
+                                      C.c_void_p(out_ptr) if out_ptr else None), "rt_render")
+        self._shape = (nRows, width, 4)
+        if not sync:
+            return None
+        self.sync()
+        if out_ptr:
+            return None
+        return self.read_rgba()
+
+    def run_compute(self, pc, width, height):
+        """Frame semantics of draw()/run_compute (src/vk_engine.cpp:1782,1812-1814)."""
+        t = pc.rayTraceParams
+        if self.totalSamples >= t.sampleLimit:
+            return None
+        pc.frameCount = self._frameNumber
+        img = self.render(pc, width, height)
+        if t.singleRender:
+            self.totalSamples = t.sampleLimit
+        else:
+            self.totalSamples += t.raysPerPixel
+        if t.progressive:
+            self._frameNumber += 1
+        return img
+
+    def sync(self):
+        self._check(self._l.rt_sync(self._h), "rt_sync")
+
+    def read_rgba(self):
+        out = np.empty(self._shape, dtype=np.float32)
+        self._check(self._l.rt_read_rgba_f32(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), out.size),
+                    "rt_read_rgba_f32")
+        return out
+
+    def read_rgba8_srgb(self):
+        out = np.empty(self._shape, dtype=np.uint8)
+        self._check(self._l.rt_read_rgba8_srgb(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size),
+                    "rt_read_rgba8_srgb")
+        return out
+
+    def trace_rays(self, origins, dirs):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        hits = (RtHit * o.shape[0])()
+        fp = C.POINTER(C.c_float)
+        self._check(self._l.rt_trace_rays(self._h, o.shape[0], o.ctypes.data_as(fp), d.ctypes.data_as(fp), hits),
+                    "rt_trace_rays")
+        return hits
+
+    def counters(self):
+        c = RtCounters()
+        self._check(self._l.rt_get_counters(self._h, C.byref(c)), "rt_get_counters")
+        return {n: getattr(c, n) for n, _ in RtCounters._fields_}
+
+    def reset_counters(self):
+        self._check(self._l.rt_reset_counters(self._h), "rt_reset_counters")
+
+    def set_profiling(self, on):
+        self._check(self._l.rt_set_profiling(self._h, 1 if on else 0), "rt_set_profiling")
+
+    def trace_time_ms(self):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self._l.rt_get_trace_time_ms(self._h, C.byref(ms), C.byref(n)), "rt_get_trace_time_ms")
+        return ms.value, n.value
+
+    def selftest(self):
+        b = C.c_uint32()
+        self._check(self._l.rt_device_selftest(self._h, C.byref(b)), "rt_device_selftest")
+        return b.value
+
+    def copy_bandwidth_gbps(self, nbytes=1 << 30, iters=10):
+        g = C.c_double()
+        self._check(self._l.rt_measure_copy_bandwidth(self._h, nbytes, iters, C.byref(g)), "copy bandwidth")
+        return g.value
+
+
+def hits_to_numpy(hits):
+    """RtHit array -> dict of numpy arrays."""
+    n = len(hits)
+    raw = np.frombuffer(hits, dtype=np.uint8).reshape(n, C.sizeof(RtHit))
+    f = raw.view(np.float32).reshape(n, -1)
+    u = raw.view(np.uint32).reshape(n, -1)
+    return dict(dst=f[:, 0].copy(), didHit=u[:, 1].copy(), isSphere=u[:, 2].copy(), objectHitIndex=u[:, 3].copy(),
+                triHitIndex=u[:, 4].copy(), materialIndex=u[:, 5].copy(), frontFace=u[:, 6].copy(),
+                hitPoint=f[:, 7:10].copy(), normal=f[:, 10:13].copy(), boxTests=u[:, 13].copy(),
+                triTests=u[:, 14].copy())
