@@ -112,7 +112,7 @@ void rows_of(const float* m, float4* out) {
 int ensure_state(rt_ctx* c, uint32_t nPixels) {
     if (c->capacity >= nPixels && c->stateBuf.p) return 0;
     const size_t stride = (((size_t)nPixels * 4) + 255) & ~(size_t)255;  // bytes per array
-    const int nArrays = 49;
+    const int nArrays = 46;
     int rc = dev_alloc(c, c->stateBuf, stride * nArrays);
     if (rc) return rc;
     char* base = (char*)c->stateBuf.p;

@@ -475,7 +475,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
         uint32_t j = jraw & 0x7fffffffu;
         const bool pending = (jraw >> 31) != 0u;
 
-        const float t = ps.hitT[RAY_MAIN][slot];
         const uint32_t obj = ps.hitObj[RAY_MAIN][slot];
         refRays = 1;  // this segment's calculateIntersections (raytrace.comp:496)
 
