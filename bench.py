@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the wavefront path tracer on the BASELINE.json workload.
+
+A "step" is one dispatch of the hot path (rt_render = the reference's
+run_compute + raytrace.comp) over the whole 1920x1080 Sponza frame at --spp
+samples per pixel, with frameCount advancing per step as in the reference's
+progressive mode (src/vk_engine.cpp:1812-1814). With N GPUs the framebuffer is
+tiled by interleaved rows (rank r renders rows r, r+N, ...), the scene is
+replicated, there is no mid-frame traffic, and each step ends with one RCCL
+gather of the fp32 strips to rank 0 (total work fixed => "strong" scaling).
+
+value   = reference-semantics rays / s: 1 ray = 1 calculateIntersections call
+          of shaders/raytrace.comp (4 per diffuse segment).
+          `unique_mrays_per_s` beside it counts only the closest-hit queries
+          the GPU actually executed (duplicate NEE probe merged, probes of
+          terminated paths skipped) — the roofline uses only executed work.
+roofline: algorithmic bytes (32 B per box test + 36 B per triangle test +
+          100 B per reported hit, counters summed by the traversal kernel
+          itself) / HIP-event time of the traversal kernel launches.
+cpu_baseline: the scalar oracle (oracle/, a port of the shader) timed on this
+          host's cores on a bounded sample of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="sponza", choices=["cornell", "bunny", "dragon", "sponza", "sponza_dragons"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket traversal launches with HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as ge
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not os.path.exists(ge.LIB):
+        ge.build()
+    from ray_tracer_amd import engine, scenes, tiling
+
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    W, H = args.width, args.height
+    scene, label = scenes.CONFIGS[args.scene]()
+    cam = scenes.sponza_camera if args.scene.startswith("sponza") else engine.push_constants
+    pc = cam(W, H, raysPerPixel=args.spp, progressive=1, singleRender=0)
+
+    r = engine.Renderer(local)
+    if r.selftest() != 0x0F:
+        raise SystemExit("device deterministic-math self-test failed")
+    r.upload_scene(scene)
+    rows = tiling.rows_of_rank(H, rank, world)
+    strip = torch.zeros((len(rows), W, 4), dtype=torch.float32, device=f"cuda:{local}")
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}") if rank == 0 else None
+
+    def step(i):
+        pc.frameCount = i
+        r.render(pc, W, H, row0=rank, rowStride=world, nRows=len(rows), out_ptr=strip.data_ptr(), sync=True)
+        if world > 1:
+            tiling.gather_frame(strip, frame, H, world, rank)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    r.reset_counters()
+    r.set_profiling(not args.no_profile)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    trace_ms, trace_launches = r.trace_time_ms()
+    r.set_profiling(False)
+    cnt = r.counters()
+
+    keys = ["boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments"]
+    vec = torch.tensor([float(cnt[k]) for k in keys] + [dt, trace_ms, float(trace_launches)], dtype=torch.float64,
+                       device=f"cuda:{local}")
+    if world > 1:
+        mx = vec.clone()
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dt = float(mx[7])
+    tot = {k: float(vec[i]) for i, k in enumerate(keys)}
+    sum_trace_ms, sum_launches = float(vec[8]), float(vec[9])
+
+    if rank == 0:
+        alg_bytes = 32.0 * tot["boxTests"] + 36.0 * tot["triTests"] + 100.0 * tot["raysHit"]
+        # per GPU: the kernel's algorithmic bytes per launch / its average launch duration
+        achieved = (alg_bytes / max(sum_launches, 1.0)) / ((sum_trace_ms / max(sum_launches, 1.0)) * 1e-3) / 1e9 if sum_trace_ms > 0 else None
+        out = {
+            "metric": "Mrays/s (reference-semantics closest-hit queries) at 1920x1080 Sponza",
+            "value": tot["raysReference"] / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene} ({label}), {W}x{H}, {args.spp} spp/step, bounceLimit 8, "
+                                   f"rows interleaved over {world} GPU(s)" + (", RCCL gather per step" if world > 1 else ""),
+                       "scene": args.scene, "assets": label, "width": W, "height": H, "spp_per_step": args.spp},
+            "unique_mrays_per_s": tot["raysTraced"] / dt / 1e6,
+            "spp_per_s": tot["paths"] / (W * H) / dt,
+            "paths": tot["paths"], "segments": tot["segments"],
+            "box_tests_per_ray": tot["boxTests"] / max(tot["raysTraced"], 1), "tri_tests_per_ray": tot["triTests"] / max(tot["raysTraced"], 1),
+            "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes / max(sum_launches, 1.0),
+                         "avg_launch_ms": sum_trace_ms / max(sum_launches, 1.0), "launches": sum_launches,
+                         "trace_share_of_step": (sum_trace_ms / world) / (dt * 1e3)},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(scene, pc, W, H, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, pc, W, H, args):
+    """The scalar oracle on this host's cores, on every k-th row of the same frame."""
+    from oracle import pyoracle
+    threads = os.cpu_count() or 1
+    pc.frameCount = 0
+    probe_rows = 2
+    stride = H // probe_rows
+    t = time.perf_counter()
+    _, c = pyoracle.render(scene, pc, W, H, row0=stride // 2, rowStride=stride, nRows=probe_rows, threads=threads)
+    dt = max(time.perf_counter() - t, 1e-3)
+    n_rows = int(max(probe_rows, min(H, probe_rows * args.cpu_seconds / dt)))
+    stride = max(1, H // n_rows)
+    n_rows = min(n_rows, (H + stride - 1) // stride)
+    t = time.perf_counter()
+    _, c = pyoracle.render(scene, pc, W, H, row0=0, rowStride=stride, nRows=n_rows, threads=threads)
+    dt = time.perf_counter() - t
+    return {"value": c["raysReference"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{n_rows} of {H} rows (every {stride}th) of the same {W}x{H} frame at {args.spp} spp, "
+                      f"{c['raysReference']} rays in {dt:.1f} s",
+            "unique_mrays_per_s": c["raysTraced"] / dt / 1e6}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built():
+    """Build librt_amd.so (hipcc cross-compiles gfx950 without a GPU) and the oracle once."""
+    import __graft_entry__ as ge
+    ge.build()
+    return ge
+
+
+@pytest.fixture(scope="session")
+def renderer(built):
+    """One device context for all GPU tests (single process, single GPU)."""
+    from ray_tracer_amd import engine
+    r = engine.Renderer(0)
+    yield r
+    r.close()

@@ -1,0 +1,213 @@
+"""GPU parity tests: the HIP wavefront pipeline (through the C ABI) against the
+scalar CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): pixels within 1e-4 relative fp32. Because both
+sides evaluate the same IEEE operations in the same order (rt_det_math.h), the
+tests ask for more: bit-identical pixels, hit records and box/triangle
+counters. The 1e-4 tolerance is asserted first so a failure says which bar
+broke."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from ray_tracer_amd import engine, scenes
+
+from util import assert_hits_equal, cornell_scene, model_scene, seeded_rays
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4  # the north_star tolerance
+
+
+def _render_both(r, scene, pc, W, H, **tile):
+    r.upload_scene(scene)
+    r.reset_counters()
+    img = r.render(pc, W, H, **tile)
+    cnt = r.counters()
+    ref, rc = pyoracle.render(scene, pc, W, H, **tile)
+    return img, cnt, ref, rc
+
+
+def _check(img, cnt, ref, rc):
+    assert img.shape == ref.shape
+    assert np.allclose(img, ref, rtol=RTOL, atol=1e-7, equal_nan=True), \
+        f"{int((~np.isclose(img, ref, rtol=RTOL, atol=1e-7)).sum())} values beyond 1e-4"
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), "pixels not bit-identical"
+    for k in ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments"):
+        assert cnt[k] == rc[k], f"counter {k}: gpu {cnt[k]} oracle {rc[k]}"
+    assert rc["stackOverflow"] == 0
+
+
+def test_device_selftest(renderer):
+    assert renderer.selftest() == 0x0F
+
+
+def test_cornell_c1_config(renderer):
+    """C1: Cornell + dielectric/mirror/diffuse spheres, 4 spp (reduced to 160x160 for the oracle)."""
+    s = cornell_scene(True)
+    W = H = 160
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=4)
+    _check(*_render_both(renderer, s, pc, W, H))
+
+
+def test_cornell_frame_seeds_and_rays_per_pixel(renderer):
+    s = cornell_scene(False)
+    W, H = 96, 64
+    for frame in (0, 1, 7):
+        pc = engine.push_constants(W, H, raysPerPixel=3, frameCount=frame)
+        _check(*_render_both(renderer, s, pc, W, H))
+
+
+@pytest.mark.parametrize("bounce", [0, 1, 5, 8, 13])
+def test_bounce_limits(renderer, bounce):
+    s = cornell_scene(True)
+    W, H = 80, 60
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3, bounceLimit=bounce)
+    _check(*_render_both(renderer, s, pc, W, H))
+
+
+def test_bunny_diffuse_and_mirror(renderer):
+    for mat in (0, 4, 5):
+        s = model_scene("bunny.obj", material=mat)
+        W, H = 128, 96
+        pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2)
+        _check(*_render_both(renderer, s, pc, W, H))
+
+
+def test_klein_bottle_35k_tris(renderer):
+    s = model_scene("klein_bottle.obj", material=4, scale=0.5, position=(0.0, -0.2, 0.0), spheres=True)
+    W, H = 128, 96
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2)
+    _check(*_render_both(renderer, s, pc, W, H))
+
+
+def test_multi_material_obj_with_mtl(renderer):
+    import os
+    s = engine.Scene()
+    s.prepare_storage_buffers()
+    s.read_obj(os.path.join(engine.ASSET_DIR, "bobadog", "bobadog.obj"),
+               engine.placement(position=(0, 0.3, 0), scale=0.35, rotation=(0, 160, 0)), 0)
+    W, H = 96, 96
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2)
+    _check(*_render_both(renderer, s, pc, W, H))
+
+
+def test_environment_light_and_camera(renderer):
+    s = cornell_scene(True)
+    W, H = 96, 54
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3, environmentOn=True, cameraAngles=(-12.0, 25.0, 5.0),
+                               pos=(0.8, -0.9, -3.0), fov=80.0)
+    _check(*_render_both(renderer, s, pc, W, H))
+
+
+def test_sponza_standin_small(renderer):
+    s, label = scenes.sponza(0, ntris=20000)
+    assert label == "synthetic-20000-tris"
+    W, H = 96, 54
+    pc = scenes.sponza_camera(W, H, singleRender=1, sampleLimit=2)
+    _check(*_render_both(renderer, s, pc, W, H))
+
+
+def test_tiling_is_invisible(renderer):
+    """Interleaved row strips (the multi-GPU partition) reproduce the full frame bit for bit."""
+    s = cornell_scene(True)
+    W, H = 64, 50
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2)
+    renderer.upload_scene(s)
+    full = renderer.render(pc, W, H)
+    for world in (2, 3, 8):
+        out = np.zeros_like(full)
+        for rank in range(world):
+            n = len(range(rank, H, world))
+            out[rank::world] = renderer.render(pc, W, H, row0=rank, rowStride=world, nRows=n)
+        assert np.array_equal(out.view(np.uint32), full.view(np.uint32))
+    # and the oracle agrees on a strip
+    ref, _ = pyoracle.render(s, pc, W, H, row0=1, rowStride=3, nRows=len(range(1, H, 3)))
+    assert np.array_equal(ref.view(np.uint32), full[1::3].view(np.uint32))
+
+
+def test_debug_heatmaps_and_progressive(renderer):
+    s = model_scene("bunny.obj")
+    W, H = 64, 48
+    for dbg in (0, 1, 2):
+        pc = engine.push_constants(W, H, raysPerPixel=1, debug=dbg, boxCap=60, triangleCap=20)
+        _check(*_render_both(renderer, s, pc, W, H))
+    # progressive: frame k blends 1/(k+1) into the fp32 buffer
+    renderer.upload_scene(s)
+    prev = None
+    for k in range(3):
+        pc = engine.push_constants(W, H, raysPerPixel=2, progressive=1, frameCount=k)
+        img = renderer.render(pc, W, H)
+        ref, _ = pyoracle.render(s, pc, W, H, prev=prev)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+        prev = ref
+
+
+def test_zero_samples_is_magenta(renderer):
+    s = cornell_scene(False)
+    W, H = 16, 8
+    pc = engine.push_constants(W, H, raysPerPixel=0)
+    _check(*_render_both(renderer, s, pc, W, H))
+
+
+@pytest.mark.parametrize("name", ["cornell", "bunny", "klein"])
+def test_trace_rays_hit_records(renderer, name):
+    """calculateIntersections per ray: t, object, triangle, frontFace, point, normal and counters."""
+    s = {"cornell": lambda: cornell_scene(True), "bunny": lambda: model_scene("bunny.obj"),
+         "klein": lambda: model_scene("klein_bottle.obj", scale=0.5, position=(0, -0.2, 0))}[name]()
+    o, d = seeded_rays(4096, seed=hash(name) % 1000)
+    renderer.upload_scene(s)
+    g = engine.hits_to_numpy(renderer.trace_rays(o, d))
+    c = engine.hits_to_numpy(pyoracle.trace_rays(s, o, d))
+    assert c["didHit"].sum() > 1000
+    assert_hits_equal(g, c)
+
+
+def test_update_buffers(renderer):
+    """update_buffer semantics: edit materials / spheres / object transforms in place."""
+    s = cornell_scene(True)
+    W, H = 64, 48
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2)
+    renderer.upload_scene(s)
+    a = renderer.render(pc, W, H)
+    s.set_sphere(1, (0.5, 0.1, 0.0), 0.4, 1)   # mirror sphere becomes red diffuse
+    renderer.update_spheres(s)
+    b = renderer.render(pc, W, H)
+    ref, _ = pyoracle.render(s, pc, W, H)
+    assert not np.array_equal(a, b)
+    assert np.array_equal(b.view(np.uint32), ref.view(np.uint32))
+
+
+def test_error_paths(built):
+    r = engine.Renderer(0)
+    pc = engine.push_constants(8, 8)
+    with pytest.raises(engine.RtError):
+        r._counts = {"spheres": 0, "objects": 0}
+        r.render(pc, 8, 8)  # before upload
+    with pytest.raises(engine.RtError):
+        engine.Renderer(4096)  # no such device
+    r.close()
+
+
+def test_full_size_properties_1080p(renderer):
+    """BASELINE-size frame (1920x1080): size-independent properties instead of a CPU oracle pass:
+    (1) two interleaved half-frames stitch to the full frame bit for bit;
+    (2) counters obey the shader's accounting: raysReference = segments + 3 * diffuse bounces and
+        raysTraced <= raysReference; paths = pixels * spp;
+    (3) every k-th row agrees with the oracle bit for bit."""
+    s, _ = scenes.sponza(0, ntris=60000)
+    W, H = 1920, 1080
+    pc = scenes.sponza_camera(W, H, singleRender=1, sampleLimit=1)
+    renderer.upload_scene(s)
+    renderer.reset_counters()
+    full = renderer.render(pc, W, H)
+    cnt = renderer.counters()
+    assert cnt["paths"] == W * H
+    assert cnt["raysTraced"] <= cnt["raysReference"]
+    assert (cnt["raysReference"] - cnt["segments"]) % 3 == 0
+    assert np.isfinite(full).all() and (full[..., 3] == 1).all()
+    halves = np.zeros_like(full)
+    for rank in range(2):
+        halves[rank::2] = renderer.render(pc, W, H, row0=rank, rowStride=2, nRows=H // 2)
+    assert np.array_equal(halves.view(np.uint32), full.view(np.uint32))
+    ref, _ = pyoracle.render(s, pc, W, H, row0=7, rowStride=135, nRows=8)
+    assert np.array_equal(ref.view(np.uint32), full[7::135].view(np.uint32))
