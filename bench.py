@@ -147,14 +147,14 @@ def main():
 def cpu_baseline(scene, pc, W, H, args):
     """The scalar oracle on this host's cores, on every k-th row of the same frame."""
     from oracle import pyoracle
-    threads = os.cpu_count() or 1
+    threads = pyoracle.effective_cpus()
     pc.frameCount = 0
-    probe_rows = 2
-    stride = H // probe_rows
+    # calibrate on 4 rows spread over the frame, then size the sample for ~cpu_seconds
+    probe_rows = 4
     t = time.perf_counter()
-    _, c = pyoracle.render(scene, pc, W, H, row0=stride // 2, rowStride=stride, nRows=probe_rows, threads=threads)
-    dt = max(time.perf_counter() - t, 1e-3)
-    n_rows = int(max(probe_rows, min(H, probe_rows * args.cpu_seconds / dt)))
+    pyoracle.render(scene, pc, W, H, row0=H // 8, rowStride=H // probe_rows, nRows=probe_rows, threads=threads)
+    per_row = max(time.perf_counter() - t, 1e-3) / probe_rows
+    n_rows = int(max(probe_rows, min(H, args.cpu_seconds / per_row)))
     stride = max(1, H // n_rows)
     n_rows = min(n_rows, (H + stride - 1) // stride)
     t = time.perf_counter()

@@ -22,6 +22,23 @@ class OracleCounters(C.Structure):
         "boxTests", "triTests", "raysTraced", "raysHit", "paths", "segments", "stackOverflow")]
 
 
+def effective_cpus():
+    """CPUs this process may actually use: affinity mask and cgroup quota, not the host's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def build():
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
 
@@ -64,7 +81,7 @@ def render(scene, pc, width, height, row0=0, rowStride=1, nRows=None, threads=No
     out = np.zeros((nRows, width, 4), dtype=np.float32) if prev is None else np.ascontiguousarray(prev, np.float32).copy()
     cnt = OracleCounters()
     if threads is None:
-        threads = os.cpu_count() or 1
+        threads = effective_cpus()
     rc = lib().oracle_render(C.byref(a), C.byref(pc), width, height, row0, rowStride, nRows,
                              out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(cnt), int(threads))
     if rc != 0:

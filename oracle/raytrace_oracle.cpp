@@ -489,14 +489,19 @@ int oracle_render(const RtSceneArrays* scene, const PushConstants* pc, uint32_t 
     Scene sc = make_scene(scene, pc->rayTraceParams.sphereCount, pc->rayTraceParams.objectCount);
     if (threads < 1) threads = 1;
     std::vector<Totals> totals(threads);
-    std::atomic<uint32_t> next{0};
+    // work items are 64-pixel runs of a row so that many threads stay busy on few rows
+    const uint32_t chunk = 64, chunksPerRow = (width + chunk - 1) / chunk;
+    const uint64_t nChunks = (uint64_t)nRows * chunksPerRow;
+    std::atomic<uint64_t> next{0};
     auto worker = [&](int tid) {
         PathCtx c{sc, *pc, totals[tid]};
         for (;;) {
-            uint32_t k = next.fetch_add(1);
-            if (k >= nRows) break;
+            uint64_t w = next.fetch_add(1);
+            if (w >= nChunks) break;
+            uint32_t k = (uint32_t)(w / chunksPerRow), x0 = (uint32_t)(w % chunksPerRow) * chunk;
             uint32_t gy = row0 + k * rowStride;
-            for (uint32_t gx = 0; gx < width; gx++) pixel_main(c, gx, gy, width, height, rgba + ((size_t)k * width + gx) * 4);
+            uint32_t x1 = x0 + chunk < width ? x0 + chunk : width;
+            for (uint32_t gx = x0; gx < x1; gx++) pixel_main(c, gx, gy, width, height, rgba + ((size_t)k * width + gx) * 4);
         }
     };
     std::vector<std::thread> pool;

@@ -211,3 +211,28 @@ def test_full_size_properties_1080p(renderer):
     assert np.array_equal(halves.view(np.uint32), full.view(np.uint32))
     ref, _ = pyoracle.render(s, pc, W, H, row0=7, rowStride=135, nRows=8)
     assert np.array_equal(ref.view(np.uint32), full[7::135].view(np.uint32))
+
+
+def test_gpu_against_committed_golden_fixtures(renderer):
+    """The HIP path against tests/golden without running the oracle."""
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(g, "cornell_c1_64x64_4spp.npz"), allow_pickle=False)
+    renderer.upload_scene(cornell_scene(True))
+    renderer.reset_counters()
+    img = renderer.render(engine.push_constants(64, 64, singleRender=1, sampleLimit=4), 64, 64)
+    assert np.allclose(img, z["rgba"], rtol=RTOL, atol=1e-7)
+    assert np.array_equal(img.view(np.uint32), z["rgba"].view(np.uint32))
+    cnt = renderer.counters()
+    gold = dict(zip([str(k) for k in z["counter_names"]], [int(v) for v in z["counters"]]))
+    for k in ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments"):
+        assert cnt[k] == gold[k], k
+    z = np.load(os.path.join(g, "bunny908_64x48_2spp_frame3.npz"), allow_pickle=False)
+    renderer.upload_scene(model_scene("bunny.obj"))
+    img = renderer.render(engine.push_constants(64, 48, raysPerPixel=2, frameCount=3), 64, 48)
+    assert np.array_equal(img.view(np.uint32), z["rgba"].view(np.uint32))
+    for name, sc in (("cornell", cornell_scene(True)), ("bunny908", model_scene("bunny.obj"))):
+        z = np.load(os.path.join(g, f"hits_{name}_1024.npz"), allow_pickle=False)
+        renderer.upload_scene(sc)
+        h = engine.hits_to_numpy(renderer.trace_rays(z["origins"], z["dirs"]))
+        assert_hits_equal(h, {k: z[k] for k in h})
