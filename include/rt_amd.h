@@ -278,6 +278,10 @@ int  rt_reset_counters(rt_ctx* ctx);
  * launch count since the last reset (synchronises). */
 int  rt_set_profiling(rt_ctx* ctx, int enabled);
 int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
+/* Performance knobs that never change results: "trace_variant" (0 = one ray per
+ * lane, 1 = persistent waves with refill, default), "refill" (idle lanes that
+ * trigger a refill, 1..64), "blocks_per_cu" (0 = occupancy query). */
+int  rt_set_tuning(rt_ctx* ctx, const char* key, int value);
 /* device self-test of the deterministic-math build (must equal RT_SELFTEST_EXPECT) */
 int  rt_device_selftest(rt_ctx* ctx, uint32_t* bitsOut);
 uint32_t rt_host_selftest(void);

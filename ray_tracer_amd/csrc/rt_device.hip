@@ -58,6 +58,13 @@ struct rt_ctx {
     uint64_t traceLaunches = 0;
     uint64_t traceLaunchesTotal = 0;
 
+    // tuning (rt_set_tuning)
+    int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
+    int refill = 24;        // k_trace_pw: idle lanes that trigger a refill
+    int blocksPerCU = 0;    // k_trace_pw: 0 = occupancy query
+    int numCUs = 256;
+    int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase
+
     int fail(const std::string& m) { error = m; return -1; }
     int hip(hipError_t e, const char* what) {
         if (e == hipSuccess) return 0;
@@ -160,13 +167,26 @@ int ensure_state(rt_ctx* c, uint32_t nPixels) {
 }
 
 template <int STACK>
-void launch_trace_t(rt_ctx* c, uint32_t blocks, const TraceArgs& ta) {
-    hipLaunchKernelGGL((k_trace<STACK>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, ta);
+void launch_trace_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
+    if (c->traceVariant == 0) {
+        uint32_t blocks = (maxRays + RT_BLOCK - 1) / RT_BLOCK;
+        hipLaunchKernelGGL((k_trace<STACK>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, ta);
+        return;
+    }
+    int perCU = c->blocksPerCU;
+    if (perCU <= 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
+    }
+    uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
+    uint32_t blocks = std::min((maxRays + RT_BLOCK - 1) / RT_BLOCK, resident);
+    TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refill, ta.perRayBox, ta.perRayTri, ta.counters,
+                   c->phaseStats ? (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)) : nullptr};
+    hipLaunchKernelGGL((k_trace_pw<STACK>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
 }
 
+// the work counter (counts[4]) must be zero when this is called
 int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     if (maxRays == 0) return 0;
-    uint32_t blocks = (maxRays + RT_BLOCK - 1) / RT_BLOCK;
     EventPair* ev = nullptr;
     if (c->profiling) {
         if (c->evUsed == c->evPool.size()) {
@@ -179,12 +199,12 @@ int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
         RT_HIP(c, hipEventRecord(ev->a, c->stream));
     }
     const uint32_t d = c->maxLeafDepth;
-    if (d <= 8) launch_trace_t<8>(c, blocks, ta);
-    else if (d <= 16) launch_trace_t<16>(c, blocks, ta);
-    else if (d <= 24) launch_trace_t<24>(c, blocks, ta);
-    else if (d <= 32) launch_trace_t<32>(c, blocks, ta);
-    else if (d <= 48) launch_trace_t<48>(c, blocks, ta);
-    else launch_trace_t<64>(c, blocks, ta);
+    if (d <= 8) launch_trace_t<8>(c, maxRays, ta);
+    else if (d <= 16) launch_trace_t<16>(c, maxRays, ta);
+    else if (d <= 24) launch_trace_t<24>(c, maxRays, ta);
+    else if (d <= 32) launch_trace_t<32>(c, maxRays, ta);
+    else if (d <= 48) launch_trace_t<48>(c, maxRays, ta);
+    else launch_trace_t<64>(c, maxRays, ta);
     RT_HIP(c, hipGetLastError());
     if (ev) RT_HIP(c, hipEventRecord(ev->b, c->stream));
     c->traceLaunchesTotal++;
@@ -225,9 +245,13 @@ int rt_create(int device, rt_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { delete c; return -5; }
     c->stream = c->ownStream;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount;
+    }
     if (hipHostMalloc((void**)&c->hostCounts, 64, hipHostMallocDefault) != hipSuccess) { delete c; return -6; }
-    if (dev_alloc(c, c->counterBuf, sizeof(DevCounters)) != 0) { delete c; return -7; }
-    (void)hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters), c->stream);
+    if (dev_alloc(c, c->counterBuf, sizeof(DevCounters) + 64) != 0) { delete c; return -7; }
+    (void)hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 64, c->stream);
     (void)hipStreamSynchronize(c->stream);
     *out = c;
     return 0;
@@ -304,7 +328,15 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
         const RootInfo& r = c->rootOf[o[i].bvhIndex];
         if (r.idx == 0xffffffffu) return c->fail("object.bvhIndex does not point at a mesh root of the uploaded BVH");
         if (o[i].materialIndex >= std::max(c->sc.materialCount, 1u)) return c->fail("object.materialIndex out of range");
-        meta[i] = make_uint4(r.idx, r.cnt, o[i].materialIndex, o[i].bvhIndex);
+        // exact identity inverse: the traversal may reuse the world-space ray (k_trace_pw)
+        static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        bool isIdent = true;
+        for (int r4 = 0; r4 < 3; r4++) {
+            const float4& q = inv[3 * (size_t)i + r4];
+            const float qq[4] = {q.x, q.y, q.z, q.w};
+            for (int k4 = 0; k4 < 4; k4++) isIdent = isIdent && (qq[k4] == ident[r4 * 4 + k4]);
+        }
+        meta[i] = make_uint4(r.idx, r.cnt, o[i].materialIndex, isIdent ? 1u : 0u);
     }
     int rc = upload(c, c->objInvBuf, inv.data(), inv.size() * sizeof(float4));
     if (rc) return rc;
@@ -501,8 +533,8 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
 
     if (fp.samples > 0) {
         // counts: [0],[1] active paths of buffer 0/1; [2],[3] rays of buffer 0/1
-        c->hostCounts[0] = nPixels; c->hostCounts[1] = 0; c->hostCounts[2] = nPixels; c->hostCounts[3] = 0;
-        RT_HIP(c, hipMemcpyAsync(counts, c->hostCounts, 16, hipMemcpyHostToDevice, c->stream));
+        c->hostCounts[0] = nPixels; c->hostCounts[1] = 0; c->hostCounts[2] = nPixels; c->hostCounts[3] = 0; c->hostCounts[4] = 0;
+        RT_HIP(c, hipMemcpyAsync(counts, c->hostCounts, 20, hipMemcpyHostToDevice, c->stream));
         RT_HIP(c, hipStreamSynchronize(c->stream));
 
         uint32_t ubActive = nPixels;  // active paths never increase
@@ -510,7 +542,7 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
         const int checkEvery = 8;
         for (uint64_t it = 0;; it++) {
             const int nxt = cur ^ 1;
-            hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, c->stream, counts + nxt, counts + 2 + nxt);
+            hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, c->stream, counts + nxt, counts + 2 + nxt, counts + 4);
             TraceArgs ta{c->q.rays[cur], counts + 2 + cur, nullptr, nullptr, dc};
             uint64_t ubRays = std::min<uint64_t>((uint64_t)ubActive * 3, (uint64_t)nPixels * 3);
             if ((rc = launch_trace(c, (uint32_t)ubRays, ta))) { c->sc = saved; return rc; }
@@ -586,8 +618,8 @@ int rt_trace_rays(rt_ctx* c, uint32_t n, const float* origins, const float* dirs
     uint32_t* prb = (uint32_t*)c->scratchBuf.p;
     uint32_t* prt = prb + n;
     RtHit* dh = (RtHit*)((char*)c->scratchBuf.p + (((size_t)n * 8 + 255) & ~(size_t)255));
-    c->hostCounts[0] = n;
-    RT_HIP(c, hipMemcpyAsync(c->q.counts, c->hostCounts, 4, hipMemcpyHostToDevice, c->stream));
+    c->hostCounts[0] = n; c->hostCounts[1] = 0; c->hostCounts[2] = 0; c->hostCounts[3] = 0; c->hostCounts[4] = 0;
+    RT_HIP(c, hipMemcpyAsync(c->q.counts, c->hostCounts, 20, hipMemcpyHostToDevice, c->stream));
     RT_HIP(c, hipMemsetAsync(c->ps.statBox, 0, (size_t)n * 4, c->stream));
     RT_HIP(c, hipMemsetAsync(c->ps.statTri, 0, (size_t)n * 4, c->stream));
     TraceArgs ta{nullptr, c->q.counts, prb, prt, (DevCounters*)c->counterBuf.p};
@@ -608,13 +640,20 @@ int rt_get_counters(rt_ctx* c, RtCounters* out) {
     out->boxTests = h.boxTests; out->triTests = h.triTests; out->raysTraced = h.raysTraced; out->raysHit = h.raysHit;
     out->raysReference = h.raysReference; out->paths = h.paths; out->segments = h.segments;
     out->traceLaunches = c->traceLaunchesTotal;
+    if (c->phaseStats) {
+        unsigned long long ps[8];
+        RT_HIP(c, hipMemcpy(ps, (char*)c->counterBuf.p + sizeof(DevCounters), sizeof(ps), hipMemcpyDeviceToHost));
+        static const char* nm[4] = {"refill", "setup", "interior", "leaf"};
+        for (int k = 0; k < 4; k++)
+            fprintf(stderr, "[phase_stats] %-8s rounds %12llu lanes %14llu avg active %.1f\n", nm[k], ps[k], ps[4 + k], ps[k] ? (double)ps[4 + k] / ps[k] : 0.0);
+    }
     return 0;
 }
 
 int rt_reset_counters(rt_ctx* c) {
     if (!c) return -1;
     RT_HIP(c, hipSetDevice(c->device));
-    RT_HIP(c, hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters), c->stream));
+    RT_HIP(c, hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 64, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     int rc = harvest_events(c);
     c->traceMs = 0.0; c->traceLaunches = 0; c->traceLaunchesTotal = 0;
@@ -636,6 +675,17 @@ int rt_get_trace_time_ms(rt_ctx* c, double* ms, uint64_t* launches) {
     if (ms) *ms = c->traceMs;
     if (launches) *launches = c->traceLaunches;
     return rc;
+}
+
+int rt_set_tuning(rt_ctx* c, const char* key, int value) {
+    if (!c || !key) return -1;
+    std::string k(key);
+    if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
+    else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; }
+    else if (k == "phase_stats") { c->phaseStats = value != 0; }
+    else if (k == "blocks_per_cu") { if (value < 0 || value > 8) return c->fail("blocks_per_cu: 0..8"); c->blocksPerCU = value; }
+    else return c->fail("unknown tuning key " + k);
+    return 0;
 }
 
 int rt_device_selftest(rt_ctx* c, uint32_t* bitsOut) {

@@ -304,6 +304,9 @@ class Renderer:
         self._check(self._l.rt_get_trace_time_ms(self._h, C.byref(ms), C.byref(n)), "rt_get_trace_time_ms")
         return ms.value, n.value
 
+    def set_tuning(self, key, value):
+        self._check(self._l.rt_set_tuning(self._h, key.encode(), int(value)), "rt_set_tuning")
+
     def selftest(self):
         b = C.c_uint32()
         self._check(self._l.rt_device_selftest(self._h, C.byref(b)), "rt_device_selftest")
