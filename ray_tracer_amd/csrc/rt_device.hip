@@ -60,7 +60,8 @@ struct rt_ctx {
 
     // tuning (rt_set_tuning)
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
-    int refill = 24;        // k_trace_pw: idle lanes that trigger a refill
+    int refill = 16;        // k_trace_pw: idle lanes that trigger a refill
+    int wSetup = 8, wLeaf = 8;  // k_trace_pw: vote weights in eighths (interior = 8)
     int blocksPerCU = 0;    // k_trace_pw: 0 = occupancy query
     int numCUs = 256;
     int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase
@@ -175,13 +176,14 @@ void launch_trace_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     }
     int perCU = c->blocksPerCU;
     if (perCU <= 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, false>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
     }
     uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
     uint32_t blocks = std::min((maxRays + RT_BLOCK - 1) / RT_BLOCK, resident);
-    TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refill, ta.perRayBox, ta.perRayTri, ta.counters,
-                   c->phaseStats ? (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)) : nullptr};
-    hipLaunchKernelGGL((k_trace_pw<STACK>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refill, (uint32_t)c->wSetup, (uint32_t)c->wLeaf,
+                   ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters))};
+    if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    else hipLaunchKernelGGL((k_trace_pw<STACK, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
 }
 
 // the work counter (counts[4]) must be zero when this is called
@@ -385,22 +387,31 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
     }
 
     std::vector<float4> nodes((size_t)std::max(devCount, 2u) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<uint32_t> leafFirst(std::max(devCount, 1u), 0u);
+    // W0 of a node: child-pair index (interior) or the leaf reference the kernels push and decode
+    auto node_word = [&](uint32_t nidx) -> uint32_t {
+        const BVHNode& b = s->bvhNodes[nidx];
+        if (b.triCount == 0) return c->nodeRemap[b.index];
+        if (b.triCount <= 7u && b.index <= RT_LEAF_IDX_MASK) return RT_LEAF_BIT | (b.triCount << RT_LEAF_CNT_SHIFT) | b.index;
+        return RT_LEAF_BIT | c->nodeRemap[nidx];
+    };
+    if (devCount > RT_LEAF_IDX_MASK) return c->fail("BVH too large (node index needs more than 28 bits)");
     for (uint32_t nidx = 0; nidx < nNodes; nidx++) {
         const BVHNode& b = s->bvhNodes[nidx];
-        uint32_t idx = b.index;
         if (b.triCount == 0) {
-            if (idx + 1 >= nNodes) return c->fail("BVH child index out of range");
-            idx = c->nodeRemap[idx];
-            if (idx & 1u) return c->fail("internal: child pair not 64-byte aligned (BVH not built in pairs)");
+            if (b.index + 1 >= nNodes) return c->fail("BVH child index out of range");
+            if (c->nodeRemap[b.index] & 1u) return c->fail("internal: child pair not 64-byte aligned (BVH not built in pairs)");
         } else if ((uint64_t)b.index + b.triCount > nTris) {
             return c->fail("BVH leaf triangle range out of bounds");
         }
+        const uint32_t w0 = node_word(nidx);
         float4 lo = make_float4(b.boundsX[0], b.boundsY[0], b.boundsZ[0], 0.f);
         float4 hi = make_float4(b.boundsX[1], b.boundsY[1], b.boundsZ[1], 0.f);
-        memcpy(&lo.w, &idx, 4);
+        memcpy(&lo.w, &w0, 4);
         memcpy(&hi.w, &b.triCount, 4);
         nodes[2 * (size_t)c->nodeRemap[nidx]] = lo;
         nodes[2 * (size_t)c->nodeRemap[nidx] + 1] = hi;
+        leafFirst[c->nodeRemap[nidx]] = b.triCount ? b.index : 0u;
     }
 
     // ---- deepest leaf per mesh decides the LDS stack size
@@ -411,7 +422,7 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
         std::vector<std::pair<uint32_t, uint32_t>> st;
         for (uint32_t root : roots) {
             const BVHNode& rb = s->bvhNodes[root];
-            rootOf[root] = RootInfo{rb.triCount ? rb.index : c->nodeRemap[rb.index], rb.triCount};
+            rootOf[root] = RootInfo{node_word(root), rb.triCount};
             st.clear();
             st.emplace_back(root, 0u);
             size_t visited = 0;
@@ -445,7 +456,7 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
     }
 
     for (auto& b : c->sceneBufs) dev_free(b);
-    c->sceneBufs.assign(3, DevBuf());
+    c->sceneBufs.assign(4, DevBuf());
     int rc;
     if ((rc = upload(c, c->sceneBufs[0], nodes.data(), nodes.size() * sizeof(float4)))) return rc;
     if ((rc = upload(c, c->sceneBufs[1], tpos.data(), tpos.size() * sizeof(float4)))) return rc;
@@ -453,6 +464,8 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
     c->sc.nodes = (const float4*)c->sceneBufs[0].p;
     c->sc.triPos = (const float4*)c->sceneBufs[1].p;
     c->sc.triNrm = (const float4*)c->sceneBufs[2].p;
+    if ((rc = upload(c, c->sceneBufs[3], leafFirst.data(), leafFirst.size() * 4))) return rc;
+    c->sc.leafFirst = (const uint32_t*)c->sceneBufs[3].p;
     c->sc.nodeCount = devCount;
     c->sc.triCount = nTris;
 
@@ -682,6 +695,8 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     std::string k(key);
     if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
     else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; }
+    else if (k == "w_setup") { if (value < 1 || value > 512) return c->fail("w_setup: 1..512"); c->wSetup = value; }
+    else if (k == "w_leaf") { if (value < 1 || value > 512) return c->fail("w_leaf: 1..512"); c->wLeaf = value; }
     else if (k == "phase_stats") { c->phaseStats = value != 0; }
     else if (k == "blocks_per_cu") { if (value < 0 || value > 8) return c->fail("blocks_per_cu: 0..8"); c->blocksPerCU = value; }
     else return c->fail("unknown tuning key " + k);

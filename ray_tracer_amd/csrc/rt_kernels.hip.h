@@ -34,7 +34,10 @@
 
 // ---------------------------------------------------------------- scene in HBM
 // All arrays are read-only during a render.
-//   nodes   : 2 x float4 per BVH node  {min.xyz, index} {max.xyz, triCount}
+//   nodes   : 2 x float4 per BVH node  {min.xyz, W0} {max.xyz, triCount}
+//             W0 = index of the child pair (interior), or a ready-made leaf
+//             reference LEAF|count<<28|firstTriangle (count <= 7), or
+//             LEAF|nodeIndex for bigger leaves (first triangle in leafFirst[])
 //             children of an interior node are adjacent and 64-B aligned, so
 //             one interior visit is one 64-B fetch (the reference re-reads the
 //             popped node and both children: 96 B, raytrace.comp:306,326-327)
@@ -48,6 +51,7 @@
 //   spheres : float4 {center, radius} + uint material
 struct DevScene {
     const float4* nodes;
+    const uint32_t* leafFirst;  // first triangle of a leaf, per node (read only for leaves with > 7 triangles)
     const float4* triPos;
     const float4* triNrm;
     const float4* objInv;
@@ -206,6 +210,18 @@ __device__ __forceinline__ float box_intersect(float4 lo, float4 hi, rt_vec3 ro,
     return hit ? (tNear > 0.f ? tNear : 0.f) : RT_MISS_DST;
 }
 
+// ---------------------------------------------------------------- leaf references
+#define RT_LEAF_CNT_SHIFT 28
+#define RT_LEAF_IDX_MASK 0x0fffffffu
+__device__ __forceinline__ void leaf_from_ref(const DevScene& sc, uint32_t ref, uint32_t& first, uint32_t& cnt) {
+    cnt = (ref >> RT_LEAF_CNT_SHIFT) & 7u;
+    first = ref & RT_LEAF_IDX_MASK;
+    if (cnt == 0) {  // big leaf: `first` is the node
+        cnt = __float_as_uint(sc.nodes[2 * (size_t)first + 1].w);
+        first = sc.leafFirst[first];
+    }
+}
+
 // ---------------------------------------------------------------- k_trace
 // One lane per ray. Each lane walks the object list and each object's BVH on
 // its own (no wave-wide object loop), with the same visit order as the shader:
@@ -258,9 +274,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
                 if (sp > 0) {
                     uint32_t ref = stack[(--sp) * RT_WAVE];
                     if (ref & RT_LEAF_BIT) {
-                        uint32_t nd = ref & ~RT_LEAF_BIT;
-                        curIdx = __float_as_uint(sc.nodes[2 * nd].w);
-                        curCnt = __float_as_uint(sc.nodes[2 * nd + 1].w);
+                        leaf_from_ref(sc, ref, curIdx, curCnt);
                     } else {
                         curIdx = ref;
                         curCnt = 0;
@@ -274,6 +288,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
                     inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
                     curIdx = meta.x;
                     curCnt = meta.y;
+                    if (curCnt) leaf_from_ref(sc, meta.x, curIdx, curCnt);
                     obj++;
                 }
                 have = true;
@@ -295,15 +310,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
                 bool nearA = d1 <= d2;
                 float dNear = nearA ? d1 : d2;
                 float dFar = nearA ? d2 : d1;
-                uint32_t nIdx = __float_as_uint(nearA ? lo1.w : lo2.w), nCnt = __float_as_uint(nearA ? hi1.w : hi2.w);
-                uint32_t fIdx = __float_as_uint(nearA ? lo2.w : lo1.w), fCnt = __float_as_uint(nearA ? hi2.w : hi1.w);
+                uint32_t nW = __float_as_uint(nearA ? lo1.w : lo2.w), nCnt = __float_as_uint(nearA ? hi1.w : hi2.w);
+                uint32_t fW = __float_as_uint(nearA ? lo2.w : lo1.w);
                 if (dFar < best) {
-                    uint32_t farNode = curIdx + (nearA ? 1u : 0u);
-                    stack[sp * RT_WAVE] = fCnt ? (RT_LEAF_BIT | farNode) : fIdx;
+                    stack[sp * RT_WAVE] = fW;
                     sp++;
                 }
-                if (dNear < best) { curIdx = nIdx; curCnt = nCnt; }
-                else have = false;
+                if (dNear < best) {
+                    curIdx = nW; curCnt = nCnt;
+                    if (nCnt) leaf_from_ref(sc, nW, curIdx, curCnt);
+                } else have = false;
             }
         }
 
@@ -346,21 +362,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
 //     component is zero, negative-zero or non-finite; other rays take the
 //     general path).
 enum { ST_IDLE = 0, ST_SETUP = 1, ST_INTERIOR = 2, ST_LEAF = 3 };
-#define RT_LEAF_CNT_SHIFT 28
-#define RT_LEAF_IDX_MASK 0x0fffffffu
-
 struct TracePwArgs {
     const uint32_t* queue;
     const uint32_t* count;
     uint32_t* head;           // work counter, zeroed before the launch
     uint32_t refill;          // re-arm idle lanes when at least this many are idle
+    uint32_t wSetup, wLeaf;   // vote weights in eighths (interior = 8)
     uint32_t* perRayBox;
     uint32_t* perRayTri;
     DevCounters* counters;
     unsigned long long* phaseStats;  // optional [8]: rounds and active lanes per phase (diagnostic)
 };
 
-template <int STACK>
+template <int STACK, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * STACK * RT_WAVE];
     uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * STACK * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
@@ -378,25 +392,61 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_pw(DevScene sc, PathState ps
     bool exhausted = false;  // wave-uniform
     uint32_t dbgRounds[4] = {0, 0, 0, 0}, dbgLanes[4] = {0, 0, 0, 0};  // refill, setup, interior, leaf (wave-uniform)
 
-    // pop the next node of this lane, or move on to the next object / finish
+    auto enter_leaf = [&](uint32_t ref) {
+        uint32_t first, cnt;
+        leaf_from_ref(sc, ref, first, cnt);
+        curIdx = first; curEnd = first + cnt; rayTri += cnt;
+        st = ST_LEAF;
+    };
+    bool atWorld = false;                     // tro/trd/inv hold the world-space ray
+    uint32_t nxW = 0, nxCnt = 0, nxFlags = 0;  // objMeta of object `obj`, fetched ahead of its use
+
+    auto finish_ray = [&]() {
+        const uint32_t slot = id >> 2, kind = id & 3u;
+        ps.hitT[kind][slot] = best;
+        ps.hitObj[kind][slot] = bestObj;
+        if (kind == RAY_MAIN) {
+            ps.hitTri[slot] = bestTri;
+            ps.statBox[slot] += rayBox;
+            ps.statTri[slot] += rayTri;
+        }
+        if (ta.perRayBox) { ta.perRayBox[qidx] = rayBox; ta.perRayTri[qidx] = rayTri; }
+        totBox += rayBox; totTri += rayTri;
+        totHits += (bestObj != RT_HIT_NONE) ? 1u : 0u;
+        st = ST_IDLE;
+    };
+    // enter the root of object `obj` (its meta is in nx*), then fetch the next object's meta
+    auto enter_root = [&]() {
+        const uint32_t w = nxW, cnt = nxCnt;
+        obj++;
+        if (obj < sc.objectCount) {
+            const uint4 m = sc.objMeta[obj];
+            nxW = m.x; nxCnt = m.y; nxFlags = m.w;
+        }
+        if (cnt) enter_leaf(w);
+        else { curIdx = w; st = ST_INTERIOR; }
+    };
+    // Next node of this lane: from its stack; else the next object (identity
+    // transforms are entered right here with register moves only, general ones
+    // go through the setup step); else the ray is finished.
     auto pop = [&]() {
         if (sp > 0) {
             uint32_t ref = stack[(--sp) * RT_WAVE];
             if (ref & RT_LEAF_BIT) {
-                uint32_t cnt = (ref >> RT_LEAF_CNT_SHIFT) & 7u;
-                uint32_t idx = ref & RT_LEAF_IDX_MASK;
-                if (cnt == 0) {  // big leaf: idx is the node
-                    cnt = __float_as_uint(sc.nodes[2 * idx + 1].w);
-                    idx = __float_as_uint(sc.nodes[2 * idx].w);
-                }
-                curIdx = idx; curEnd = idx + cnt; rayTri += cnt;
-                st = ST_LEAF;
+                enter_leaf(ref);
             } else {
                 curIdx = ref;
                 st = ST_INTERIOR;
             }
+        } else if (obj < sc.objectCount) {
+            if ((nxFlags & 1u) && plain) {
+                if (!atWorld) { tro = ro; trd = rd; inv = invW; atWorld = true; }
+                enter_root();
+            } else {
+                st = ST_SETUP;
+            }
         } else {
-            st = ST_SETUP;  // setup also detects the end of the object list
+            finish_ray();
         }
     };
 
@@ -410,7 +460,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_pw(DevScene sc, PathState ps
             if (lane_id() == 0) base = atomicAdd(ta.head, nIdle);
             base = __shfl(base, 0, RT_WAVE);
             if (base + nIdle >= n) exhausted = true;
-            if (ta.phaseStats) { dbgRounds[0]++; dbgLanes[0] += nIdle; }
+            if (STATS) { dbgRounds[0]++; dbgLanes[0] += nIdle; }
             if (st == ST_IDLE) {
                 uint32_t qi = base + lanes_below(mIdle);
                 if (qi < n) {
@@ -430,9 +480,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_pw(DevScene sc, PathState ps
                     plain = ((rt_f2u(rd.x) & M) - 1u < E - 1u) && ((rt_f2u(rd.y) & M) - 1u < E - 1u) && ((rt_f2u(rd.z) & M) - 1u < E - 1u) &&
                             ((rt_f2u(ro.x) & M) < E) && ((rt_f2u(ro.y) & M) < E) && ((rt_f2u(ro.z) & M) < E) &&
                             rt_f2u(ro.x) != 0x80000000u && rt_f2u(ro.y) != 0x80000000u && rt_f2u(ro.z) != 0x80000000u;
-                    obj = 0; sp = 0; rayBox = 0; rayTri = 0;
-                    st = ST_SETUP;
+                    obj = 0; sp = 0; rayBox = 0; rayTri = 0; atWorld = false;
                     totRays++;
+                    if (sc.objectCount) {
+                        const uint4 m = sc.objMeta[0];
+                        nxW = m.x; nxCnt = m.y; nxFlags = m.w;
+                    }
+                    pop();
                 }
             }
         }
@@ -442,13 +496,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_pw(DevScene sc, PathState ps
         const uint32_t nI = __popcll(__ballot(st == ST_INTERIOR));
         const uint32_t nL = __popcll(__ballot(st == ST_LEAF));
         if ((nS | nI | nL) == 0) continue;  // only reachable right before the exit test
-        if (ta.phaseStats) {
-            if (nI >= nL && nI >= nS) { dbgRounds[2]++; dbgLanes[2] += nI; }
-            else if (nL >= nS) { dbgRounds[3]++; dbgLanes[3] += nL; }
+        // weighted vote: a cheap step that feeds lanes back into the interior state may run with fewer lanes
+        const uint32_t scS = nS * ta.wSetup, scI = nI * 8u, scL = nL * ta.wLeaf;
+        const bool runI = scI >= scL && scI >= scS;
+        const bool runL = !runI && scL >= scS;
+        if (STATS) {
+            if (runI) { dbgRounds[2]++; dbgLanes[2] += nI; }
+            else if (runL) { dbgRounds[3]++; dbgLanes[3] += nL; }
             else { dbgRounds[1]++; dbgLanes[1] += nS; }
         }
 
-        if (nI >= nL && nI >= nS) {
+        if (runI) {
             // ---------------- interior step: both children of the pair at curIdx
             if (st == ST_INTERIOR) {
                 const float4* pr = sc.nodes + 2 * (size_t)curIdx;
@@ -458,24 +516,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_pw(DevScene sc, PathState ps
                 rayBox += 2;
                 const bool nearA = d1 <= d2;
                 const float dNear = nearA ? d1 : d2, dFar = nearA ? d2 : d1;
-                const uint32_t nIdx = __float_as_uint(nearA ? lo1.w : lo2.w), nCnt = __float_as_uint(nearA ? hi1.w : hi2.w);
-                const uint32_t fIdx = __float_as_uint(nearA ? lo2.w : lo1.w), fCnt = __float_as_uint(nearA ? hi2.w : hi1.w);
-                if (dFar < best) {
-                    uint32_t ref;
-                    if (fCnt == 0) ref = fIdx;
-                    else if (fCnt <= 7u && fIdx <= RT_LEAF_IDX_MASK) ref = RT_LEAF_BIT | (fCnt << RT_LEAF_CNT_SHIFT) | fIdx;
-                    else ref = RT_LEAF_BIT | (curIdx + (nearA ? 1u : 0u));
-                    stack[sp * RT_WAVE] = ref;
+                const uint32_t nW = __float_as_uint(nearA ? lo1.w : lo2.w), nCnt = __float_as_uint(nearA ? hi1.w : hi2.w);
+                const uint32_t fW = __float_as_uint(nearA ? lo2.w : lo1.w);
+                if (dFar < best) {  // the word is ready-made: pair index or leaf reference
+                    stack[sp * RT_WAVE] = fW;
                     sp++;
                 }
                 if (dNear < best) {
-                    curIdx = nIdx;
-                    if (nCnt) { curEnd = nIdx + nCnt; rayTri += nCnt; st = ST_LEAF; }
+                    if (nCnt) enter_leaf(nW);
+                    else curIdx = nW;
                 } else {
                     pop();
                 }
             }
-        } else if (nL >= nS) {
+        } else if (runL) {
             // ---------------- leaf step: one triangle
             if (st == ST_LEAF) {
                 const uint32_t j = curIdx;
@@ -486,41 +540,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_pw(DevScene sc, PathState ps
                 if (curIdx == curEnd) pop();
             }
         } else {
-            // ---------------- setup step: next object, or finish the ray
+            // ---------------- setup step: enter an object with a general transform
             if (st == ST_SETUP) {
-                if (obj >= sc.objectCount) {
-                    const uint32_t slot = id >> 2, kind = id & 3u;
-                    ps.hitT[kind][slot] = best;
-                    ps.hitObj[kind][slot] = bestObj;
-                    if (kind == RAY_MAIN) {
-                        ps.hitTri[slot] = bestTri;
-                        ps.statBox[slot] += rayBox;
-                        ps.statTri[slot] += rayTri;
-                    }
-                    if (ta.perRayBox) { ta.perRayBox[qidx] = rayBox; ta.perRayTri[qidx] = rayTri; }
-                    totBox += rayBox; totTri += rayTri;
-                    totHits += (bestObj != RT_HIT_NONE) ? 1u : 0u;
-                    st = ST_IDLE;
-                } else {
-                    const uint4 meta = sc.objMeta[obj];
-                    if ((meta.w & 1u) && plain) {
-                        tro = ro; trd = rd; inv = invW;
-                    } else {
-                        float4 r0 = sc.objInv[3 * obj], r1 = sc.objInv[3 * obj + 1], r2 = sc.objInv[3 * obj + 2];
-                        trd = xform_dir_rows(r0, r1, r2, rd);
-                        tro = xform_point_rows(r0, r1, r2, ro);
-                        inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
-                    }
-                    obj++;
-                    curIdx = meta.x;
-                    if (meta.y) { curEnd = meta.x + meta.y; rayTri += meta.y; st = ST_LEAF; }
-                    else st = ST_INTERIOR;
-                }
+                float4 r0 = sc.objInv[3 * obj], r1 = sc.objInv[3 * obj + 1], r2 = sc.objInv[3 * obj + 2];
+                trd = xform_dir_rows(r0, r1, r2, rd);
+                tro = xform_point_rows(r0, r1, r2, ro);
+                inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
+                atWorld = false;
+                enter_root();
             }
         }
     }
 
-    if (ta.phaseStats && lane_id() == 0) {
+    if (STATS && lane_id() == 0) {
         for (int k = 0; k < 4; k++) {
             atomicAdd(&ta.phaseStats[k], (unsigned long long)dbgRounds[k]);
             atomicAdd(&ta.phaseStats[4 + k], (unsigned long long)dbgLanes[k]);
