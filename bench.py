@@ -136,6 +136,13 @@ def main():
                          "avg_launch_ms": sum_trace_ms / max(sum_launches, 1.0), "launches": sum_launches,
                          "trace_share_of_step": (sum_trace_ms / world) / (dt * 1e3)},
         }
+        # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes of this same command
+        # (tools/pmc_traffic.py -> profiles/); PMC counters cannot be read from inside the process
+        tfile = os.path.join(ROOT, "profiles", f"traffic_k_trace_{args.scene}_{W}x{H}_{args.spp}spp.json")
+        if world == 1 and os.path.exists(tfile):
+            with open(tfile) as f:
+                out["roofline"]["traffic"] = json.load(f)["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = os.path.relpath(tfile, ROOT)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(scene, pc, W, H, args)
         print(json.dumps(out), flush=True)

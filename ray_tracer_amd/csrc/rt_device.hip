@@ -60,8 +60,8 @@ struct rt_ctx {
 
     // tuning (rt_set_tuning)
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
-    int refill = 16;        // k_trace_pw: idle lanes that trigger a refill
-    int wSetup = 8, wLeaf = 8;  // k_trace_pw: vote weights in eighths (interior = 8)
+    int refill = 12;        // k_trace_pw: idle lanes that trigger a refill
+    int wSetup = 16, wLeaf = 8; // k_trace_pw: vote weights in eighths (interior = 8)
     int blocksPerCU = 0;    // k_trace_pw: 0 = occupancy query
     int numCUs = 256;
     int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase

@@ -19,6 +19,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--spp", type=int, default=2)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--phase-stats", action="store_true")
+ap.add_argument("--bounce", type=int, default=8)
 ap.add_argument("--ntris", type=int, default=0, help="sponza stand-in triangle count (0 = default)")
 ap.add_argument("--variants", default="v0;v1,refill=8;v1,refill=16;v1,refill=24;v1,refill=32;v1,refill=48")
 args = ap.parse_args()
@@ -26,7 +27,7 @@ args = ap.parse_args()
 scene, label = scenes.sponza(0, ntris=args.ntris) if (args.ntris and args.scene == 'sponza') else scenes.CONFIGS[args.scene]()
 cam = scenes.sponza_camera if args.scene.startswith("sponza") else engine.push_constants
 W, H = args.width, args.height
-pc = cam(W, H, singleRender=1, sampleLimit=args.spp)
+pc = cam(W, H, singleRender=1, sampleLimit=args.spp, bounceLimit=args.bounce)
 r = engine.Renderer(0)
 r.upload_scene(scene)
 if args.phase_stats:
