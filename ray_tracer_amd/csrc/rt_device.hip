@@ -65,6 +65,7 @@ struct rt_ctx {
     int blocksPerCU = 0;    // k_trace_pw: 0 = occupancy query
     int numCUs = 256;
     int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase
+    bool pixStats = false;  // this dispatch needs per-pixel box/triangle counts (debug heat maps)
 
     int fail(const std::string& m) { error = m; return -1; }
     int hip(hipError_t e, const char* what) {
@@ -176,14 +177,17 @@ void launch_trace_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     }
     int perCU = c->blocksPerCU;
     if (perCU <= 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, false>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, false, false>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
     }
     uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
     uint32_t blocks = std::min((maxRays + RT_BLOCK - 1) / RT_BLOCK, resident);
     TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refill, (uint32_t)c->wSetup, (uint32_t)c->wLeaf,
                    ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters))};
-    if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
-    else hipLaunchKernelGGL((k_trace_pw<STACK, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    // per-ray counters are only needed for the pixel heat maps (debug >= 0) and rt_trace_rays
+    const bool pix = c->pixStats || ta.perRayBox;
+    if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, true, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    else if (pix) hipLaunchKernelGGL((k_trace_pw<STACK, true, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    else hipLaunchKernelGGL((k_trace_pw<STACK, false, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
 }
 
 // the work counter (counts[4]) must be zero when this is called
@@ -392,10 +396,10 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
     auto node_word = [&](uint32_t nidx) -> uint32_t {
         const BVHNode& b = s->bvhNodes[nidx];
         if (b.triCount == 0) return c->nodeRemap[b.index];
-        if (b.triCount <= 7u && b.index <= RT_LEAF_IDX_MASK) return RT_LEAF_BIT | (b.triCount << RT_LEAF_CNT_SHIFT) | b.index;
+        if (b.triCount <= 7u && b.index + b.triCount <= 0x0ffffff0u) return RT_LEAF_BIT | (b.triCount << RT_LEAF_CNT_SHIFT) | b.index;
         return RT_LEAF_BIT | c->nodeRemap[nidx];
     };
-    if (devCount > RT_LEAF_IDX_MASK) return c->fail("BVH too large (node index needs more than 28 bits)");
+    if (devCount > 0x0ffffff0u) return c->fail("BVH too large (node index needs more than 28 bits)");
     for (uint32_t nidx = 0; nidx < nNodes; nidx++) {
         const BVHNode& b = s->bvhNodes[nidx];
         if (b.triCount == 0) {
@@ -531,6 +535,7 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     fp.triCap = td.triangleCap;
     fp.env = pc->environment;
 
+    c->pixStats = td.debug >= 0;
     DevScene sc = c->sc;
     sc.sphereCount = td.sphereCount;
     sc.objectCount = td.objectCount;

@@ -351,108 +351,72 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
 //   * persistent waves pull rays from the queue with one atomic per refill and
 //     re-arm idle lanes when at least `refill` lanes are idle, so a wave does
 //     not drain down to its slowest ray;
-//   * every lane is in one of three states (object setup / interior node /
-//     leaf triangle) and each round the wave votes (__ballot + popcount) for
-//     the most populated state and executes only that step, with one triangle
-//     per leaf step;
-//   * far-leaf stack entries carry (first triangle, count<=7) in the word, so a
-//     pop needs no memory read; bigger leaves fall back to the node index;
-//   * objects whose transform is exactly the identity reuse the world-space
-//     ray and 1/dir (bit-identical to multiplying by the identity when no
-//     component is zero, negative-zero or non-finite; other rays take the
-//     general path).
-enum { ST_IDLE = 0, ST_SETUP = 1, ST_INTERIOR = 2, ST_LEAF = 3 };
+//   * a lane's whole traversal state is one word `cur`: a child-pair index
+//     (interior), a leaf reference, or a marker (needs a node / general
+//     object setup pending / idle). Each round the wave votes (__ballot +
+//     popcount, weighted) for interior, leaf or setup work and executes only
+//     that step — one triangle per leaf step — and a common tail hands every
+//     lane that ran out of work its next node: from its LDS stack, else the
+//     root of the next object, else the ray is stored and the lane idles;
+//   * leaf references (first triangle, count <= 7) are ready-made in the node
+//     words, so pushes and pops move one word and need no memory read;
+//   * objects whose transform is exactly the identity are entered in the tail
+//     with register moves only: they reuse the world-space ray and 1/dir
+//     (bit-identical to multiplying by the identity when no component is
+//     zero, negative-zero or non-finite; other rays take the general path).
+//     The next object's metadata is fetched one object ahead.
+#define RT_CUR_IDLE 0xffffffffu
+#define RT_CUR_NEED 0xfffffffeu
+#define RT_CUR_SETUP 0xfffffffdu
+#define RT_CUR_LEAF_MAX 0xfffffff0u  // leaf references are below the markers
+
 struct TracePwArgs {
     const uint32_t* queue;
     const uint32_t* count;
     uint32_t* head;           // work counter, zeroed before the launch
     uint32_t refill;          // re-arm idle lanes when at least this many are idle
     uint32_t wSetup, wLeaf;   // vote weights in eighths (interior = 8)
-    uint32_t* perRayBox;
+    uint32_t* perRayBox;      // PIX only
     uint32_t* perRayTri;
     DevCounters* counters;
-    unsigned long long* phaseStats;  // optional [8]: rounds and active lanes per phase (diagnostic)
+    unsigned long long* phaseStats;  // STATS only: [8] rounds and active lanes per phase
 };
 
-template <int STACK, bool STATS>
+template <int STACK, bool PIX, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * STACK * RT_WAVE];
     uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * STACK * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
     const uint32_t n = *ta.count;
 
-    uint32_t st = ST_IDLE;
+    uint32_t cur = RT_CUR_IDLE;
     uint32_t id = 0, qidx = 0;
-    rt_vec3 ro = rt_v3(0, 0, 0), rd = ro, invW = ro, tro = ro, trd = ro, inv = ro;
-    bool plain = false;  // ray eligible for the identity fast path
+    rt_vec3 tro = rt_v3(0, 0, 0), trd = tro, inv = tro;  // ray in the current object's space, 1/dir
+    bool plain = false;    // ray eligible for the identity fast path
+    bool atWorld = false;  // tro/trd/inv currently are the world-space ray
     float best = RT_MISS_DST;
     uint32_t bestObj = RT_HIT_NONE, bestTri = 0;
-    uint32_t obj = 0, sp = 0, curIdx = 0, curEnd = 0;
-    uint32_t rayBox = 0, rayTri = 0;
+    uint32_t obj = 0, sp = 0;
+    uint32_t nxW = 0, nxCnt = 0, nxFlags = 0;  // objMeta of object `obj`, fetched ahead of its use
+    uint32_t rayBox = 0, rayTri = 0;           // PIX: this ray's counters
     uint32_t totBox = 0, totTri = 0, totRays = 0, totHits = 0;
     bool exhausted = false;  // wave-uniform
-    uint32_t dbgRounds[4] = {0, 0, 0, 0}, dbgLanes[4] = {0, 0, 0, 0};  // refill, setup, interior, leaf (wave-uniform)
+    uint32_t dbgRounds[4] = {0, 0, 0, 0}, dbgLanes[4] = {0, 0, 0, 0};  // refill, setup, interior, leaf
 
-    auto enter_leaf = [&](uint32_t ref) {
-        uint32_t first, cnt;
-        leaf_from_ref(sc, ref, first, cnt);
-        curIdx = first; curEnd = first + cnt; rayTri += cnt;
-        st = ST_LEAF;
-    };
-    bool atWorld = false;                     // tro/trd/inv hold the world-space ray
-    uint32_t nxW = 0, nxCnt = 0, nxFlags = 0;  // objMeta of object `obj`, fetched ahead of its use
-
-    auto finish_ray = [&]() {
+    auto load_world_ray = [&]() {
         const uint32_t slot = id >> 2, kind = id & 3u;
-        ps.hitT[kind][slot] = best;
-        ps.hitObj[kind][slot] = bestObj;
-        if (kind == RAY_MAIN) {
-            ps.hitTri[slot] = bestTri;
-            ps.statBox[slot] += rayBox;
-            ps.statTri[slot] += rayTri;
-        }
-        if (ta.perRayBox) { ta.perRayBox[qidx] = rayBox; ta.perRayTri[qidx] = rayTri; }
-        totBox += rayBox; totTri += rayTri;
-        totHits += (bestObj != RT_HIT_NONE) ? 1u : 0u;
-        st = ST_IDLE;
+        if (kind == RAY_MAIN) { tro = ld3(ps.rayO, slot); trd = ld3(ps.rayD, slot); }
+        else { tro = ld3(ps.auxO, slot); trd = (kind == RAY_NEE) ? ld3(ps.auxDL, slot) : ld3(ps.auxDC, slot); }
     };
-    // enter the root of object `obj` (its meta is in nx*), then fetch the next object's meta
-    auto enter_root = [&]() {
-        const uint32_t w = nxW, cnt = nxCnt;
-        obj++;
+    auto fetch_next_meta = [&]() {
         if (obj < sc.objectCount) {
             const uint4 m = sc.objMeta[obj];
             nxW = m.x; nxCnt = m.y; nxFlags = m.w;
-        }
-        if (cnt) enter_leaf(w);
-        else { curIdx = w; st = ST_INTERIOR; }
-    };
-    // Next node of this lane: from its stack; else the next object (identity
-    // transforms are entered right here with register moves only, general ones
-    // go through the setup step); else the ray is finished.
-    auto pop = [&]() {
-        if (sp > 0) {
-            uint32_t ref = stack[(--sp) * RT_WAVE];
-            if (ref & RT_LEAF_BIT) {
-                enter_leaf(ref);
-            } else {
-                curIdx = ref;
-                st = ST_INTERIOR;
-            }
-        } else if (obj < sc.objectCount) {
-            if ((nxFlags & 1u) && plain) {
-                if (!atWorld) { tro = ro; trd = rd; inv = invW; atWorld = true; }
-                enter_root();
-            } else {
-                st = ST_SETUP;
-            }
-        } else {
-            finish_ray();
         }
     };
 
     for (;;) {
         // ---------------- refill
-        const unsigned long long mIdle = __ballot(st == ST_IDLE);
+        const unsigned long long mIdle = __ballot(cur == RT_CUR_IDLE);
         const uint32_t nIdle = __popcll(mIdle);
         if (nIdle == RT_WAVE && exhausted) break;
         if (!exhausted && nIdle >= ta.refill) {
@@ -461,93 +425,133 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_pw(DevScene sc, PathState ps
             base = __shfl(base, 0, RT_WAVE);
             if (base + nIdle >= n) exhausted = true;
             if (STATS) { dbgRounds[0]++; dbgLanes[0] += nIdle; }
-            if (st == ST_IDLE) {
-                uint32_t qi = base + lanes_below(mIdle);
+            if (cur == RT_CUR_IDLE) {
+                const uint32_t qi = base + lanes_below(mIdle);
                 if (qi < n) {
                     qidx = qi;
                     id = ta.queue ? ta.queue[qi] : (qi << 2);
-                    const uint32_t slot = id >> 2, kind = id & 3u;
-                    if (kind == RAY_MAIN) { ro = ld3(ps.rayO, slot); rd = ld3(ps.rayD, slot); }
-                    else { ro = ld3(ps.auxO, slot); rd = (kind == RAY_NEE) ? ld3(ps.auxDL, slot) : ld3(ps.auxDC, slot); }
+                    load_world_ray();
                     best = RT_MISS_DST; bestObj = RT_HIT_NONE; bestTri = 0;
                     for (uint32_t i = 0; i < sc.sphereCount; i++) {
-                        SphereHit h = sphere_intersect(sc.spheres[i], ro, rd);
+                        SphereHit h = sphere_intersect(sc.spheres[i], tro, trd);
                         if (h.didHit && h.dst < best) { best = h.dst; bestObj = RT_HIT_SPHERE | i; }
                     }
-                    invW = rt_v3(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
+                    inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
+                    atWorld = true;
                     // finite and non-zero direction, finite origin without negative zeros
                     const uint32_t E = 0x7f800000u, M = 0x7fffffffu;
-                    plain = ((rt_f2u(rd.x) & M) - 1u < E - 1u) && ((rt_f2u(rd.y) & M) - 1u < E - 1u) && ((rt_f2u(rd.z) & M) - 1u < E - 1u) &&
-                            ((rt_f2u(ro.x) & M) < E) && ((rt_f2u(ro.y) & M) < E) && ((rt_f2u(ro.z) & M) < E) &&
-                            rt_f2u(ro.x) != 0x80000000u && rt_f2u(ro.y) != 0x80000000u && rt_f2u(ro.z) != 0x80000000u;
-                    obj = 0; sp = 0; rayBox = 0; rayTri = 0; atWorld = false;
+                    plain = ((rt_f2u(trd.x) & M) - 1u < E - 1u) && ((rt_f2u(trd.y) & M) - 1u < E - 1u) && ((rt_f2u(trd.z) & M) - 1u < E - 1u) &&
+                            ((rt_f2u(tro.x) & M) < E) && ((rt_f2u(tro.y) & M) < E) && ((rt_f2u(tro.z) & M) < E) &&
+                            rt_f2u(tro.x) != 0x80000000u && rt_f2u(tro.y) != 0x80000000u && rt_f2u(tro.z) != 0x80000000u;
+                    obj = 0; sp = 0;
+                    if (PIX) { rayBox = 0; rayTri = 0; }
                     totRays++;
-                    if (sc.objectCount) {
-                        const uint4 m = sc.objMeta[0];
-                        nxW = m.x; nxCnt = m.y; nxFlags = m.w;
-                    }
-                    pop();
+                    fetch_next_meta();
+                    cur = RT_CUR_NEED;
                 }
             }
         }
 
         // ---------------- vote
-        const uint32_t nS = __popcll(__ballot(st == ST_SETUP));
-        const uint32_t nI = __popcll(__ballot(st == ST_INTERIOR));
-        const uint32_t nL = __popcll(__ballot(st == ST_LEAF));
-        if ((nS | nI | nL) == 0) continue;  // only reachable right before the exit test
-        // weighted vote: a cheap step that feeds lanes back into the interior state may run with fewer lanes
+        const uint32_t nI = __popcll(__ballot((int32_t)cur >= 0));
+        const uint32_t nL = __popcll(__ballot((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX));
+        const uint32_t nS = __popcll(__ballot(cur == RT_CUR_SETUP));
+        // weighted: a cheap step that feeds lanes back into the interior state may run with fewer lanes
         const uint32_t scS = nS * ta.wSetup, scI = nI * 8u, scL = nL * ta.wLeaf;
-        const bool runI = scI >= scL && scI >= scS;
-        const bool runL = !runI && scL >= scS;
+        const bool runI = nI && scI >= scL && scI >= scS;
+        const bool runL = !runI && nL && scL >= scS;
+        const bool runS = !runI && !runL && nS;
         if (STATS) {
             if (runI) { dbgRounds[2]++; dbgLanes[2] += nI; }
             else if (runL) { dbgRounds[3]++; dbgLanes[3] += nL; }
-            else { dbgRounds[1]++; dbgLanes[1] += nS; }
+            else if (runS) { dbgRounds[1]++; dbgLanes[1] += nS; }
         }
 
         if (runI) {
-            // ---------------- interior step: both children of the pair at curIdx
-            if (st == ST_INTERIOR) {
-                const float4* pr = sc.nodes + 2 * (size_t)curIdx;
-                float4 lo1 = pr[0], hi1 = pr[1], lo2 = pr[2], hi2 = pr[3];
-                float d1 = box_intersect(lo1, hi1, tro, inv);
-                float d2 = box_intersect(lo2, hi2, tro, inv);
-                rayBox += 2;
+            // ---------------- interior step: both children of the pair `cur`
+            if ((int32_t)cur >= 0) {
+                const float4* pr = sc.nodes + 2 * (size_t)cur;
+                const float4 lo1 = pr[0], hi1 = pr[1], lo2 = pr[2], hi2 = pr[3];
+                const float d1 = box_intersect(lo1, hi1, tro, inv);
+                const float d2 = box_intersect(lo2, hi2, tro, inv);
+                if (PIX) rayBox += 2; else totBox += 2;
                 const bool nearA = d1 <= d2;
                 const float dNear = nearA ? d1 : d2, dFar = nearA ? d2 : d1;
-                const uint32_t nW = __float_as_uint(nearA ? lo1.w : lo2.w), nCnt = __float_as_uint(nearA ? hi1.w : hi2.w);
-                const uint32_t fW = __float_as_uint(nearA ? lo2.w : lo1.w);
-                if (dFar < best) {  // the word is ready-made: pair index or leaf reference
+                const uint32_t nW = __float_as_uint(nearA ? lo1.w : lo2.w), fW = __float_as_uint(nearA ? lo2.w : lo1.w);
+                if (dFar < best) {  // ready-made word: pair index or leaf reference
                     stack[sp * RT_WAVE] = fW;
                     sp++;
                 }
-                if (dNear < best) {
-                    if (nCnt) enter_leaf(nW);
-                    else curIdx = nW;
-                } else {
-                    pop();
-                }
+                cur = (dNear < best) ? nW : RT_CUR_NEED;
             }
         } else if (runL) {
-            // ---------------- leaf step: one triangle
-            if (st == ST_LEAF) {
-                const uint32_t j = curIdx;
-                float4 a = sc.triPos[3 * (size_t)j], b = sc.triPos[3 * (size_t)j + 1], c = sc.triPos[3 * (size_t)j + 2];
-                TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
-                if (h.didHit && h.dst < best) { best = h.dst; bestObj = obj - 1; bestTri = j; }
-                curIdx = j + 1;
-                if (curIdx == curEnd) pop();
+            // ---------------- leaf step: one triangle (all of them for a leaf with > 7)
+            if ((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX) {
+                const uint32_t cnt = (cur >> RT_LEAF_CNT_SHIFT) & 7u;
+                uint32_t j = cur & RT_LEAF_IDX_MASK, jEnd;
+                if (cnt == 0) {  // j is the node
+                    jEnd = __float_as_uint(sc.nodes[2 * (size_t)j + 1].w);
+                    j = sc.leafFirst[j];
+                    jEnd += j;
+                    cur = RT_CUR_NEED;
+                } else {
+                    jEnd = j + 1;
+                    cur = (cnt > 1u) ? (cur + 1u - (1u << RT_LEAF_CNT_SHIFT)) : RT_CUR_NEED;
+                }
+                if (PIX) rayTri += jEnd - j; else totTri += jEnd - j;
+                for (; j < jEnd; j++) {
+                    const float4 a = sc.triPos[3 * (size_t)j], b = sc.triPos[3 * (size_t)j + 1], c = sc.triPos[3 * (size_t)j + 2];
+                    const TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
+                    if (h.didHit && h.dst < best) { best = h.dst; bestObj = obj - 1; bestTri = j; }
+                }
             }
-        } else {
-            // ---------------- setup step: enter an object with a general transform
-            if (st == ST_SETUP) {
-                float4 r0 = sc.objInv[3 * obj], r1 = sc.objInv[3 * obj + 1], r2 = sc.objInv[3 * obj + 2];
-                trd = xform_dir_rows(r0, r1, r2, rd);
-                tro = xform_point_rows(r0, r1, r2, ro);
+        } else if (runS) {
+            // ---------------- setup step: enter object `obj`, which has a general transform
+            if (cur == RT_CUR_SETUP) {
+                const float4 r0 = sc.objInv[3 * obj], r1 = sc.objInv[3 * obj + 1], r2 = sc.objInv[3 * obj + 2];
+                load_world_ray();
+                const rt_vec3 wo = tro, wd = trd;
+                trd = xform_dir_rows(r0, r1, r2, wd);
+                tro = xform_point_rows(r0, r1, r2, wo);
                 inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
                 atWorld = false;
-                enter_root();
+                cur = nxW;
+                obj++;
+                fetch_next_meta();
+            }
+        }
+
+        // ---------------- tail: next node for every lane that ran out of work
+        if (cur == RT_CUR_NEED) {
+            if (sp > 0) {
+                cur = stack[(--sp) * RT_WAVE];
+            } else if (obj < sc.objectCount) {
+                if ((nxFlags & 1u) && plain) {
+                    if (!atWorld) {  // back from a general-transform object
+                        load_world_ray();
+                        inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
+                        atWorld = true;
+                    }
+                    cur = nxW;
+                    obj++;
+                    fetch_next_meta();
+                } else {
+                    cur = RT_CUR_SETUP;
+                }
+            } else {
+                const uint32_t slot = id >> 2, kind = id & 3u;
+                ps.hitT[kind][slot] = best;
+                ps.hitObj[kind][slot] = bestObj;
+                if (kind == RAY_MAIN) {
+                    ps.hitTri[slot] = bestTri;
+                    if (PIX) { ps.statBox[slot] += rayBox; ps.statTri[slot] += rayTri; }
+                }
+                if (PIX) {
+                    if (ta.perRayBox) { ta.perRayBox[qidx] = rayBox; ta.perRayTri[qidx] = rayTri; }
+                    totBox += rayBox; totTri += rayTri;
+                }
+                totHits += (bestObj != RT_HIT_NONE) ? 1u : 0u;
+                cur = RT_CUR_IDLE;
             }
         }
     }
