@@ -65,6 +65,7 @@ struct rt_ctx {
     int blocksPerCU = 0;    // k_trace_pw: 0 = occupancy query
     int numCUs = 256;
     int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase
+    int tileSlots = 1;      // slots follow 8x8 pixel blocks instead of rows
     bool pixStats = false;  // this dispatch needs per-pixel box/triangle counts (debug heat maps)
 
     int fail(const std::string& m) { error = m; return -1; }
@@ -523,6 +524,7 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     fp.bottomLeft[0] = -fp.planeWidth / 2.f;
     fp.bottomLeft[1] = -fp.planeHeight / 2.f;
     fp.bottomLeft[2] = 0.1f;
+    fp.tiled = (c->tileSlots && (width % 8u) == 0u) ? 1u : 0u;
     fp.width = width; fp.height = height; fp.row0 = row0; fp.rowStride = rowStride; fp.nRows = nRows; fp.nPixels = nPixels;
     uint32_t lol = pc->frameCount;
     fp.startingSeed = (uint32_t)(rt_random(&lol) * 23892183.f);
@@ -702,6 +704,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; }
     else if (k == "w_setup") { if (value < 1 || value > 512) return c->fail("w_setup: 1..512"); c->wSetup = value; }
     else if (k == "w_leaf") { if (value < 1 || value > 512) return c->fail("w_leaf: 1..512"); c->wLeaf = value; }
+    else if (k == "tile_slots") { c->tileSlots = value != 0; }
     else if (k == "phase_stats") { c->phaseStats = value != 0; }
     else if (k == "blocks_per_cu") { if (value < 0 || value > 8) return c->fail("blocks_per_cu: 0..8"); c->blocksPerCU = value; }
     else return c->fail("unknown tuning key " + k);

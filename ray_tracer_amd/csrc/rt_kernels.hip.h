@@ -110,6 +110,7 @@ struct FrameParams {
     float planeWidth, planeHeight;
     float bottomLeft[3];
     uint32_t width, height, row0, rowStride, nRows, nPixels;
+    uint32_t tiled;         // 8x8 slot order (width % 8 == 0)
     uint32_t startingSeed;  // uint(random(frameCount) * 23892183)
     uint32_t samples, bounceLimit;
     uint32_t progressive, frameCount;
@@ -383,7 +384,7 @@ struct TracePwArgs {
 };
 
 template <int STACK, bool PIX, bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
+__global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * STACK * RT_WAVE];
     uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * STACK * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
     const uint32_t n = *ta.count;
@@ -659,9 +660,22 @@ __device__ __forceinline__ rt_vec3 primary_dir(const FrameParams& fp, uint32_t g
     return rt_xform_point(fp.camRot, dir);
 }
 
-__device__ __forceinline__ void slot_to_pixel(const FrameParams& fp, uint32_t slot, uint32_t& gx, uint32_t& gy) {
-    uint32_t k = slot / fp.width;
-    gx = slot - k * fp.width;
+// Slot -> pixel. Slots walk the tile's rows in 8x8 pixel blocks (one wave = one
+// block, like the reference's 8x8 workgroups, raytrace.comp:4), so the rays of a
+// wave start out coherent; a remainder of fewer than 8 rows, or a width that is
+// not a multiple of 8, falls back to row-major order. `k` is the local row.
+__device__ __forceinline__ void slot_to_pixel(const FrameParams& fp, uint32_t slot, uint32_t& gx, uint32_t& gy, uint32_t& k) {
+    const uint32_t tiledSlots = fp.tiled ? (fp.nRows & ~7u) * fp.width : 0u;
+    if (slot < tiledSlots) {
+        const uint32_t tile = slot >> 6, in = slot & 63u;
+        const uint32_t tilesPerRow = fp.width >> 3;
+        const uint32_t tyb = tile / tilesPerRow, txb = tile - tyb * tilesPerRow;
+        gx = (txb << 3) + (in & 7u);
+        k = (tyb << 3) + (in >> 3);
+    } else {
+        k = slot / fp.width;
+        gx = slot - k * fp.width;
+    }
     gy = fp.row0 + k * fp.rowStride;
 }
 
@@ -670,7 +684,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(PathState ps, Queues q, Fra
     uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (slot >= fp.nPixels) return;
     uint32_t gx, gy;
-    slot_to_pixel(fp, slot, gx, gy);
+    uint32_t krow;
+    slot_to_pixel(fp, slot, gx, gy, krow);
     st3(ps.rayO, slot, rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]));
     st3(ps.rayD, slot, primary_dir(fp, gx, gy));
     ps.rng[slot] = gy * fp.width + gx + fp.startingSeed;
@@ -855,7 +870,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
             if (s < fp.samples) {
                 // next sample of this pixel: same primary ray, RNG state runs on (:571-573)
                 uint32_t gx, gy;
-                slot_to_pixel(fp, slot, gx, gy);
+                uint32_t krow;
+                slot_to_pixel(fp, slot, gx, gy, krow);
                 ro = rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]);
                 rd = primary_dir(fp, gx, gy);
                 att = rt_v3(1.f, 1.f, 1.f);
@@ -923,7 +939,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathState ps, FrameParams 
     float fs = (float)fp.samples;
     out = rt_v3(out.x / fs, out.y / fs, out.z / fs);
     float weight = 1.f / ((float)fp.frameCount + 1.f);
-    float4 oldc = rgba[slot];
+    uint32_t gx, gy, krow;
+    slot_to_pixel(fp, slot, gx, gy, krow);
+    const size_t px = (size_t)krow * fp.width + gx;
+    float4 oldc = rgba[px];
     rt_vec3 blended = rt_add(rt_scale(rt_v3(oldc.x, oldc.y, oldc.z), 1.f - weight), rt_scale(out, weight));
     rt_vec3 fin = fp.progressive ? blended : out;
     if (rt_isnan(fin.x) || rt_isnan(fin.y) || rt_isnan(fin.z) || rt_isinf(fin.x) || rt_isinf(fin.y) || rt_isinf(fin.z))
@@ -937,7 +956,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathState ps, FrameParams 
     } else if (fp.debug == 2) {
         fin = rt_v3(s0 / boxCap, 0.f, s1 / triCap);
     }
-    rgba[slot] = make_float4(fin.x, fin.y, fin.z, 1.f);
+    rgba[px] = make_float4(fin.x, fin.y, fin.z, 1.f);
 }
 
 // ---------------------------------------------------------------- rt_trace_rays support
