@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket traversal launches with HIP events")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, default); gloo only to rehearse N ranks on ONE GPU (strips gathered through host memory)")
+    ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole frame alone and compares it with the gathered one")
     args = ap.parse_args()
 
     import numpy as np
@@ -57,9 +60,15 @@ def main():
         ge.build()
     from ray_tracer_amd import engine, scenes, tiling
 
+    rehearsal = args.backend == "gloo"
+    if rehearsal:
+        local = 0  # every rank shares GPU 0; RCCL cannot run two ranks on one device
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     W, H = args.width, args.height
     scene, label = scenes.CONFIGS[args.scene]()
@@ -72,13 +81,14 @@ def main():
     r.upload_scene(scene)
     rows = tiling.rows_of_rank(H, rank, world)
     strip = torch.zeros((len(rows), W, 4), dtype=torch.float32, device=f"cuda:{local}")
-    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}") if rank == 0 else None
+    fdev = "cpu" if rehearsal else f"cuda:{local}"
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device=fdev) if rank == 0 else None
 
     def step(i):
         pc.frameCount = i
         r.render(pc, W, H, row0=rank, rowStride=world, nRows=len(rows), out_ptr=strip.data_ptr(), sync=True)
         if world > 1:
-            tiling.gather_frame(strip, frame, H, world, rank)
+            tiling.gather_frame(strip.cpu() if rehearsal else strip, frame, H, world, rank)
 
     def fence():
         torch.cuda.synchronize()
@@ -102,7 +112,7 @@ def main():
 
     keys = ["boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments"]
     vec = torch.tensor([float(cnt[k]) for k in keys] + [dt, trace_ms, float(trace_launches)], dtype=torch.float64,
-                       device=f"cuda:{local}")
+                       device=fdev)
     if world > 1:
         mx = vec.clone()
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
@@ -145,6 +155,17 @@ def main():
                 out["roofline"]["traffic_source"] = os.path.relpath(tfile, ROOT)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(scene, pc, W, H, args)
+        if args.check and world > 1:
+            # the same frames rendered by one process must equal the stitched strips bit for bit
+            r.reset_counters()
+            solo = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
+            for i in range(args.warmup + args.steps):
+                pc.frameCount = i
+                r.render(pc, W, H, out_ptr=solo.data_ptr(), sync=True)
+            same = bool(torch.equal(solo.cpu().view(torch.int32), frame.cpu().view(torch.int32)))
+            out["check_tiled_equals_single"] = same
+            if not same:
+                raise SystemExit("tiled frame differs from the single-GPU frame")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

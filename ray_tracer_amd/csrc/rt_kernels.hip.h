@@ -366,9 +366,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
 //     (bit-identical to multiplying by the identity when no component is
 //     zero, negative-zero or non-finite; other rays take the general path).
 //     The next object's metadata is fetched one object ahead.
-#define RT_CUR_IDLE 0xffffffffu
-#define RT_CUR_NEED 0xfffffffeu
-#define RT_CUR_SETUP 0xfffffffdu
+#define RT_CUR_IDLE 0xffffffffu   // no ray
+#define RT_CUR_NEED 0xfffffffeu   // wants its next node (tail)
+#define RT_CUR_SETUP 0xfffffffdu  // entering object `obj`, which has a general transform
+#define RT_CUR_WORLD 0xfffffffcu  // back to the world-space ray after a general-transform object
+#define RT_CUR_INIT 0xfffffffbu   // new ray: load it, sphere tests, 1/dir
 #define RT_CUR_LEAF_MAX 0xfffffff0u  // leaf references are below the markers
 
 struct TracePwArgs {
@@ -376,6 +378,7 @@ struct TracePwArgs {
     const uint32_t* count;
     uint32_t* head;           // work counter, zeroed before the launch
     uint32_t refill;          // re-arm idle lanes when at least this many are idle
+    uint32_t chunk;           // most queue entries a wave reserves per atomic (guided: fewer near the end)
     uint32_t wSetup, wLeaf;   // vote weights in eighths (interior = 8)
     uint32_t* perRayBox;      // PIX only
     uint32_t* perRayTri;
@@ -391,73 +394,65 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
 
     uint32_t cur = RT_CUR_IDLE;
     uint32_t id = 0, qidx = 0;
-    rt_vec3 tro = rt_v3(0, 0, 0), trd = tro, inv = tro;  // ray in the current object's space, 1/dir
+    rt_vec3 tro = rt_v3(0, 0, 0), trd = tro, inv = tro;  // ray in the current object's space, 1/dir (written by the setup step only)
     bool plain = false;    // ray eligible for the identity fast path
     bool atWorld = false;  // tro/trd/inv currently are the world-space ray
     float best = RT_MISS_DST;
     uint32_t bestObj = RT_HIT_NONE, bestTri = 0;
     uint32_t obj = 0, sp = 0;
-    uint32_t nxW = 0, nxCnt = 0, nxFlags = 0;  // objMeta of object `obj`, fetched ahead of its use
-    uint32_t rayBox = 0, rayTri = 0;           // PIX: this ray's counters
+    uint32_t nxW = 0, nxFlags = 0;   // objMeta of object `obj`, fetched ahead of its use
+    uint32_t rayBox = 0, rayTri = 0;  // PIX: this ray's counters
     uint32_t totBox = 0, totTri = 0, totRays = 0, totHits = 0;
-    bool exhausted = false;  // wave-uniform
+    bool exhausted = false;               // wave-uniform: the queue has no entries left to reserve
+    uint32_t resBase = 0, resCount = 0;   // wave-uniform: reserved queue entries not yet dealt out
+    uint32_t nextChunk = min(ta.chunk, max(16u, n / (2u * gridDim.x * (RT_BLOCK / RT_WAVE))));
     uint32_t dbgRounds[4] = {0, 0, 0, 0}, dbgLanes[4] = {0, 0, 0, 0};  // refill, setup, interior, leaf
 
-    auto load_world_ray = [&]() {
-        const uint32_t slot = id >> 2, kind = id & 3u;
-        if (kind == RAY_MAIN) { tro = ld3(ps.rayO, slot); trd = ld3(ps.rayD, slot); }
-        else { tro = ld3(ps.auxO, slot); trd = (kind == RAY_NEE) ? ld3(ps.auxDL, slot) : ld3(ps.auxDC, slot); }
-    };
     auto fetch_next_meta = [&]() {
         if (obj < sc.objectCount) {
             const uint4 m = sc.objMeta[obj];
-            nxW = m.x; nxCnt = m.y; nxFlags = m.w;
+            nxW = m.x; nxFlags = m.w;
         }
     };
 
     for (;;) {
-        // ---------------- refill
+        // ---------------- refill: hand queue entries to idle lanes (the ray itself is loaded by the setup step).
+        // The wave reserves `chunk` entries per atomic (one hot counter saturates near 90 atomics/us) and
+        // deals them out locally.
         const unsigned long long mIdle = __ballot(cur == RT_CUR_IDLE);
         const uint32_t nIdle = __popcll(mIdle);
-        if (nIdle == RT_WAVE && exhausted) break;
-        if (!exhausted && nIdle >= ta.refill) {
-            uint32_t base = 0;
-            if (lane_id() == 0) base = atomicAdd(ta.head, nIdle);
-            base = __shfl(base, 0, RT_WAVE);
-            if (base + nIdle >= n) exhausted = true;
-            if (STATS) { dbgRounds[0]++; dbgLanes[0] += nIdle; }
+        if (nIdle == RT_WAVE && exhausted && resCount == 0) break;
+        if (nIdle >= ta.refill && (resCount || !exhausted)) {
+            if (resCount == 0) {
+                uint32_t base = 0;
+                if (lane_id() == 0) base = atomicAdd(ta.head, nextChunk);
+                base = __shfl(base, 0, RT_WAVE);
+                resBase = base;
+                resCount = base < n ? min(nextChunk, n - base) : 0u;
+                if (base + nextChunk >= n) exhausted = true;
+                // guided self-scheduling: big reservations while the queue is long, small ones near its end
+                const uint32_t left = base + nextChunk < n ? n - base - nextChunk : 0u;
+                nextChunk = min(ta.chunk, max(16u, left / (2u * gridDim.x * (RT_BLOCK / RT_WAVE))));
+            }
+            const uint32_t take = min(nIdle, resCount);
+            if (STATS) { dbgRounds[0]++; dbgLanes[0] += take; }
             if (cur == RT_CUR_IDLE) {
-                const uint32_t qi = base + lanes_below(mIdle);
-                if (qi < n) {
-                    qidx = qi;
-                    id = ta.queue ? ta.queue[qi] : (qi << 2);
-                    load_world_ray();
-                    best = RT_MISS_DST; bestObj = RT_HIT_NONE; bestTri = 0;
-                    for (uint32_t i = 0; i < sc.sphereCount; i++) {
-                        SphereHit h = sphere_intersect(sc.spheres[i], tro, trd);
-                        if (h.didHit && h.dst < best) { best = h.dst; bestObj = RT_HIT_SPHERE | i; }
-                    }
-                    inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
-                    atWorld = true;
-                    // finite and non-zero direction, finite origin without negative zeros
-                    const uint32_t E = 0x7f800000u, M = 0x7fffffffu;
-                    plain = ((rt_f2u(trd.x) & M) - 1u < E - 1u) && ((rt_f2u(trd.y) & M) - 1u < E - 1u) && ((rt_f2u(trd.z) & M) - 1u < E - 1u) &&
-                            ((rt_f2u(tro.x) & M) < E) && ((rt_f2u(tro.y) & M) < E) && ((rt_f2u(tro.z) & M) < E) &&
-                            rt_f2u(tro.x) != 0x80000000u && rt_f2u(tro.y) != 0x80000000u && rt_f2u(tro.z) != 0x80000000u;
-                    obj = 0; sp = 0;
-                    if (PIX) { rayBox = 0; rayTri = 0; }
-                    totRays++;
-                    fetch_next_meta();
-                    cur = RT_CUR_NEED;
+                const uint32_t rk = lanes_below(mIdle);
+                if (rk < take) {
+                    qidx = resBase + rk;
+                    id = ta.queue ? ta.queue[qidx] : (qidx << 2);
+                    cur = RT_CUR_INIT;
                 }
             }
+            resBase += take;
+            resCount -= take;
         }
 
         // ---------------- vote
         const uint32_t nI = __popcll(__ballot((int32_t)cur >= 0));
         const uint32_t nL = __popcll(__ballot((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX));
-        const uint32_t nS = __popcll(__ballot(cur == RT_CUR_SETUP));
-        // weighted: a cheap step that feeds lanes back into the interior state may run with fewer lanes
+        const uint32_t nS = __popcll(__ballot(cur - RT_CUR_INIT <= RT_CUR_SETUP - RT_CUR_INIT));
+        // weighted: a step that feeds lanes back into the interior state may run with fewer lanes
         const uint32_t scS = nS * ta.wSetup, scI = nI * 8u, scL = nL * ta.wLeaf;
         const bool runI = nI && scI >= scL && scI >= scS;
         const bool runL = !runI && nL && scL >= scS;
@@ -507,18 +502,49 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
                 }
             }
         } else if (runS) {
-            // ---------------- setup step: enter object `obj`, which has a general transform
-            if (cur == RT_CUR_SETUP) {
-                const float4 r0 = sc.objInv[3 * obj], r1 = sc.objInv[3 * obj + 1], r2 = sc.objInv[3 * obj + 2];
-                load_world_ray();
-                const rt_vec3 wo = tro, wd = trd;
-                trd = xform_dir_rows(r0, r1, r2, wd);
-                tro = xform_point_rows(r0, r1, r2, wo);
+            // ---------------- setup step: the only place that writes tro/trd/inv
+            //   INIT : new ray (world space, sphere tests)      -> NEED
+            //   WORLD: world-space ray again                     -> NEED
+            //   SETUP: into object `obj` with a general matrix   -> its root
+            if (cur - RT_CUR_INIT <= RT_CUR_SETUP - RT_CUR_INIT) {
+                const uint32_t slot = id >> 2, kind = id & 3u;
+                rt_vec3 wo, wd;
+                if (kind == RAY_MAIN) { wo = ld3(ps.rayO, slot); wd = ld3(ps.rayD, slot); }
+                else { wo = ld3(ps.auxO, slot); wd = (kind == RAY_NEE) ? ld3(ps.auxDL, slot) : ld3(ps.auxDC, slot); }
+                if (cur == RT_CUR_INIT) {
+                    best = RT_MISS_DST; bestObj = RT_HIT_NONE; bestTri = 0;
+                    for (uint32_t i = 0; i < sc.sphereCount; i++) {
+                        SphereHit h = sphere_intersect(sc.spheres[i], wo, wd);
+                        if (h.didHit && h.dst < best) { best = h.dst; bestObj = RT_HIT_SPHERE | i; }
+                    }
+                    // finite and non-zero direction, finite origin without negative zeros
+                    const uint32_t E = 0x7f800000u, M = 0x7fffffffu;
+                    plain = ((rt_f2u(wd.x) & M) - 1u < E - 1u) && ((rt_f2u(wd.y) & M) - 1u < E - 1u) && ((rt_f2u(wd.z) & M) - 1u < E - 1u) &&
+                            ((rt_f2u(wo.x) & M) < E) && ((rt_f2u(wo.y) & M) < E) && ((rt_f2u(wo.z) & M) < E) &&
+                            rt_f2u(wo.x) != 0x80000000u && rt_f2u(wo.y) != 0x80000000u && rt_f2u(wo.z) != 0x80000000u;
+                    obj = 0; sp = 0;
+                    if (PIX) { rayBox = 0; rayTri = 0; }
+                    totRays++;
+                    fetch_next_meta();
+                }
+                const bool general = cur == RT_CUR_SETUP;
+                if (general) {
+                    const float4 r0 = sc.objInv[3 * obj], r1 = sc.objInv[3 * obj + 1], r2 = sc.objInv[3 * obj + 2];
+                    trd = xform_dir_rows(r0, r1, r2, wd);
+                    tro = xform_point_rows(r0, r1, r2, wo);
+                } else {
+                    trd = wd;
+                    tro = wo;
+                }
                 inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
-                atWorld = false;
-                cur = nxW;
-                obj++;
-                fetch_next_meta();
+                atWorld = !general;
+                if (general) {
+                    cur = nxW;
+                    obj++;
+                    fetch_next_meta();
+                } else {
+                    cur = RT_CUR_NEED;
+                }
             }
         }
 
@@ -527,15 +553,14 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
             if (sp > 0) {
                 cur = stack[(--sp) * RT_WAVE];
             } else if (obj < sc.objectCount) {
-                if ((nxFlags & 1u) && plain) {
-                    if (!atWorld) {  // back from a general-transform object
-                        load_world_ray();
-                        inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
-                        atWorld = true;
+                if ((nxFlags & 1u) && plain) {  // identity transform: register moves only
+                    if (atWorld) {
+                        cur = nxW;
+                        obj++;
+                        fetch_next_meta();
+                    } else {
+                        cur = RT_CUR_WORLD;
                     }
-                    cur = nxW;
-                    obj++;
-                    fetch_next_meta();
                 } else {
                     cur = RT_CUR_SETUP;
                 }
