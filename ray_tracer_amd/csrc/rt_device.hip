@@ -122,38 +122,23 @@ void rows_of(const float* m, float4* out) {
 
 int ensure_state(rt_ctx* c, uint32_t nPixels) {
     if (c->capacity >= nPixels && c->stateBuf.p) return 0;
-    const size_t stride = (((size_t)nPixels * 4) + 255) & ~(size_t)255;  // bytes per array
-    const int nArrays = 46;
-    int rc = dev_alloc(c, c->stateBuf, stride * nArrays);
+    const size_t stride4 = (((size_t)nPixels * 16) + 255) & ~(size_t)255;  // bytes per float4 array
+    const size_t stride1 = (((size_t)nPixels * 4) + 255) & ~(size_t)255;
+    const int nF4 = 13, nU1 = 2;
+    int rc = dev_alloc(c, c->stateBuf, stride4 * nF4 + stride1 * nU1);
     if (rc) return rc;
     char* base = (char*)c->stateBuf.p;
     int k = 0;
-    auto nextf = [&]() { return (float*)(base + stride * (k++)); };
-    auto nextu = [&]() { return (uint32_t*)(base + stride * (k++)); };
+    auto next4 = [&]() { return (float4*)(base + stride4 * (k++)); };
     PathState& ps = c->ps;
-    for (int i = 0; i < 3; i++) ps.rayO[i] = nextf();
-    for (int i = 0; i < 3; i++) ps.rayD[i] = nextf();
-    for (int i = 0; i < 3; i++) ps.auxO[i] = nextf();
-    for (int i = 0; i < 3; i++) ps.auxDL[i] = nextf();
-    for (int i = 0; i < 3; i++) ps.auxDC[i] = nextf();
-    for (int i = 0; i < 3; i++) ps.hitT[i] = nextf();
-    for (int i = 0; i < 3; i++) ps.hitObj[i] = nextu();
-    ps.hitTri = nextu();
-    for (int i = 0; i < 3; i++) ps.att[i] = nextf();
-    for (int i = 0; i < 3; i++) ps.total[i] = nextf();
-    for (int i = 0; i < 3; i++) ps.direct[i] = nextf();
-    ps.misW = nextf();
-    for (int i = 0; i < 3; i++) ps.pendAlbedo[i] = nextf();
-    ps.pendNDotL = nextf();
-    ps.pendCosPdfL = nextf();
-    ps.pendCosPdfC = nextf();
-    for (int i = 0; i < 3; i++) ps.accum[i] = nextf();
-    ps.rng = nextu();
-    ps.sample = nextu();
-    ps.bounce = nextu();
-    ps.statBox = nextu();
-    ps.statTri = nextu();
-    if (k != nArrays) return c->fail("internal: path state array count");
+    ps.rayO = next4(); ps.rayD = next4();
+    ps.auxO = next4(); ps.auxDL = next4(); ps.auxDC = next4();
+    for (int i = 0; i < 3; i++) ps.hit[i] = next4();
+    ps.att = next4(); ps.total = next4(); ps.direct = next4();
+    ps.pendAlbedo = next4(); ps.accum = next4();
+    if (k != nF4) return c->fail("internal: path state array count");
+    ps.statBox = (uint32_t*)(base + stride4 * nF4);
+    ps.statTri = (uint32_t*)(base + stride4 * nF4 + stride1);
 
     // queues: 2 x active (n) + 2 x rays (3n) + 4 counters
     const size_t qa = (((size_t)nPixels * 4) + 255) & ~(size_t)255;
@@ -624,16 +609,14 @@ int rt_trace_rays(rt_ctx* c, uint32_t n, const float* origins, const float* dirs
     RT_HIP(c, hipSetDevice(c->device));
     int rc = ensure_state(c, n);
     if (rc) return rc;
-    std::vector<float> soa((size_t)n * 6);
-    for (uint32_t i = 0; i < n; i++)
-        for (int k = 0; k < 3; k++) {
-            soa[(size_t)k * n + i] = origins[(size_t)i * 3 + k];
-            soa[(size_t)(3 + k) * n + i] = dirs[(size_t)i * 3 + k];
-        }
-    for (int k = 0; k < 3; k++) {
-        RT_HIP(c, hipMemcpyAsync(c->ps.rayO[k], &soa[(size_t)k * n], (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-        RT_HIP(c, hipMemcpyAsync(c->ps.rayD[k], &soa[(size_t)(3 + k) * n], (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    std::vector<float4> ho(n), hd(n);
+    for (uint32_t i = 0; i < n; i++) {
+        ho[i] = make_float4(origins[(size_t)i * 3], origins[(size_t)i * 3 + 1], origins[(size_t)i * 3 + 2], 0.f);
+        hd[i] = make_float4(dirs[(size_t)i * 3], dirs[(size_t)i * 3 + 1], dirs[(size_t)i * 3 + 2], 0.f);
     }
+    RT_HIP(c, hipMemcpyAsync(c->ps.rayO, ho.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(c->ps.rayD, hd.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
     size_t need = (size_t)n * 8 + (size_t)n * sizeof(RtHit) + 256;
     if ((rc = dev_alloc(c, c->scratchBuf, need))) return rc;
     uint32_t* prb = (uint32_t*)c->scratchBuf.p;

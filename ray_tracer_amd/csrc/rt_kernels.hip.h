@@ -66,35 +66,23 @@ struct DevScene {
 // ---------------------------------------------------------------- path state (SoA, one slot per pixel)
 enum { RAY_MAIN = 0, RAY_NEE = 1, RAY_PROBE = 2 };
 
+// 16-byte records per slot: a path touches its state through a dozen dwordx4
+// accesses instead of ~85 dword accesses (k_shade is bound by the number of
+// memory instructions in flight, not by bytes).
 struct PathState {
-    // current main ray
-    float* rayO[3];
-    float* rayD[3];
-    // the two probe rays of the previous diffuse bounce (shared origin)
-    float* auxO[3];
-    float* auxDL[3];
-    float* auxDC[3];
-    // closest-hit results per ray kind
-    float* hitT[3];
-    uint32_t* hitObj[3];
-    uint32_t* hitTri;  // main ray only
-    // trace() locals (raytrace.comp:484-489)
-    float* att[3];
-    float* total[3];
-    float* direct[3];
-    float* misW;
-    // diffuseBRDF values that wait for the probe results (:446-460)
-    float* pendAlbedo[3];
-    float* pendNDotL;     // max(0, dot(n, lightSample))
-    float* pendCosPdfL;   // cosineHemispherePDF(n, lightSample)
-    float* pendCosPdfC;   // cosineHemispherePDF(n, cosineSample)
-    // main() locals (:562-573)
-    float* accum[3];
-    uint32_t* rng;
-    uint32_t* sample;
-    uint32_t* bounce;   // j; bit 31 = NEE results pending
-    uint32_t* statBox;  // stats[0] of the pixel (main-path traversals only)
-    uint32_t* statTri;  // stats[1]
+    float4* rayO;        // main ray origin            | w: misWeight (raytrace.comp:487)
+    float4* rayD;        // main ray direction         | w: RNG state bits (:564)
+    float4* auxO;        // origin of the probe rays   | w: max(0, dot(n, lightSample))          (:460)
+    float4* auxDL;       // NEE direction              | w: cosineHemispherePDF(n, lightSample)  (:448)
+    float4* auxDC;       // cosine-sample direction    | w: cosineHemispherePDF(n, cosineSample) (:454)
+    float4* hit[3];      // per ray kind: {dst, object bits, triangle bits, -}
+    float4* att;         // attenuation                | w: bounce index j, bit 31 = NEE results pending
+    float4* total;       // totalColor                 | w: samples finished for this pixel
+    float4* direct;      // directLight
+    float4* pendAlbedo;  // albedo of the previous diffuse hit
+    float4* accum;       // sum of trace() over the pixel's samples (:572)
+    uint32_t* statBox;   // stats[0] of the pixel (main-path traversals only)
+    uint32_t* statTri;   // stats[1]
 };
 
 struct Queues {
@@ -124,9 +112,9 @@ struct DevCounters {
 };
 
 // ---------------------------------------------------------------- small helpers
-__device__ __forceinline__ rt_vec3 ld3(float* const p[3], uint32_t i) { return rt_v3(p[0][i], p[1][i], p[2][i]); }
-__device__ __forceinline__ void st3(float* const p[3], uint32_t i, rt_vec3 v) { p[0][i] = v.x; p[1][i] = v.y; p[2][i] = v.z; }
 __device__ __forceinline__ rt_vec3 f4xyz(float4 v) { return rt_v3(v.x, v.y, v.z); }
+__device__ __forceinline__ float4 mk4(rt_vec3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+__device__ __forceinline__ float4 mk4u(rt_vec3 v, uint32_t w) { return make_float4(v.x, v.y, v.z, __uint_as_float(w)); }
 
 // (M * vec4(v,0)).xyz and (M * vec4(v,1)).xyz with M given as three rows
 // {m0,m4,m8,m12},{m1,m5,m9,m13},{m2,m6,m10,m14}; same sums as rt_xform_*.
@@ -255,8 +243,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
         slot = id >> 2;
         kind = id & 3u;
         rt_vec3 ro, rd;
-        if (kind == RAY_MAIN) { ro = ld3(ps.rayO, slot); rd = ld3(ps.rayD, slot); }
-        else { ro = ld3(ps.auxO, slot); rd = (kind == RAY_NEE) ? ld3(ps.auxDL, slot) : ld3(ps.auxDC, slot); }
+        if (kind == RAY_MAIN) { ro = f4xyz(ps.rayO[slot]); rd = f4xyz(ps.rayD[slot]); }
+        else { ro = f4xyz(ps.auxO[slot]); rd = f4xyz(kind == RAY_NEE ? ps.auxDL[slot] : ps.auxDC[slot]); }
 
         float best = RT_MISS_DST;
         uint32_t bestObj = RT_HIT_NONE, bestTri = 0;
@@ -324,12 +312,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
             }
         }
 
-        ps.hitT[kind][slot] = best;
-        ps.hitObj[kind][slot] = bestObj;
-        if (kind == RAY_MAIN) {
-            ps.hitTri[slot] = bestTri;
-            if (ps.statBox) { ps.statBox[slot] += nBox; ps.statTri[slot] += nTri; }
-        }
+        ps.hit[kind][slot] = make_float4(best, __uint_as_float(bestObj), __uint_as_float(bestTri), 0.f);
+        if (kind == RAY_MAIN && ps.statBox) { ps.statBox[slot] += nBox; ps.statTri[slot] += nTri; }
         if (ta.perRayBox) { ta.perRayBox[gid] = nBox; ta.perRayTri[gid] = nTri; }
         didHit = bestObj != RT_HIT_NONE;
     }
@@ -509,8 +493,8 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
             if (cur - RT_CUR_INIT <= RT_CUR_SETUP - RT_CUR_INIT) {
                 const uint32_t slot = id >> 2, kind = id & 3u;
                 rt_vec3 wo, wd;
-                if (kind == RAY_MAIN) { wo = ld3(ps.rayO, slot); wd = ld3(ps.rayD, slot); }
-                else { wo = ld3(ps.auxO, slot); wd = (kind == RAY_NEE) ? ld3(ps.auxDL, slot) : ld3(ps.auxDC, slot); }
+                if (kind == RAY_MAIN) { wo = f4xyz(ps.rayO[slot]); wd = f4xyz(ps.rayD[slot]); }
+                else { wo = f4xyz(ps.auxO[slot]); wd = f4xyz(kind == RAY_NEE ? ps.auxDL[slot] : ps.auxDC[slot]); }
                 if (cur == RT_CUR_INIT) {
                     best = RT_MISS_DST; bestObj = RT_HIT_NONE; bestTri = 0;
                     for (uint32_t i = 0; i < sc.sphereCount; i++) {
@@ -566,12 +550,8 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
                 }
             } else {
                 const uint32_t slot = id >> 2, kind = id & 3u;
-                ps.hitT[kind][slot] = best;
-                ps.hitObj[kind][slot] = bestObj;
-                if (kind == RAY_MAIN) {
-                    ps.hitTri[slot] = bestTri;
-                    if (PIX) { ps.statBox[slot] += rayBox; ps.statTri[slot] += rayTri; }
-                }
+                ps.hit[kind][slot] = make_float4(best, __uint_as_float(bestObj), __uint_as_float(bestTri), 0.f);
+                if (PIX && kind == RAY_MAIN) { ps.statBox[slot] += rayBox; ps.statTri[slot] += rayTri; }
                 if (PIX) {
                     if (ta.perRayBox) { ta.perRayBox[qidx] = rayBox; ta.perRayTri[qidx] = rayTri; }
                     totBox += rayBox; totTri += rayTri;
@@ -711,16 +691,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(PathState ps, Queues q, Fra
     uint32_t gx, gy;
     uint32_t krow;
     slot_to_pixel(fp, slot, gx, gy, krow);
-    st3(ps.rayO, slot, rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]));
-    st3(ps.rayD, slot, primary_dir(fp, gx, gy));
-    ps.rng[slot] = gy * fp.width + gx + fp.startingSeed;
-    st3(ps.att, slot, rt_v3(1.f, 1.f, 1.f));
-    st3(ps.total, slot, rt_v3(0.f, 0.f, 0.f));
-    st3(ps.direct, slot, rt_v3(0.f, 0.f, 0.f));
-    ps.misW[slot] = 1.f;
-    st3(ps.accum, slot, rt_v3(0.f, 0.f, 0.f));
-    ps.sample[slot] = 0;
-    ps.bounce[slot] = 0;
+    ps.rayO[slot] = make_float4(fp.camPos[0], fp.camPos[1], fp.camPos[2], 1.f);                          // misWeight = 1
+    ps.rayD[slot] = mk4u(primary_dir(fp, gx, gy), gy * fp.width + gx + fp.startingSeed);              // RNG seed (:564)
+    ps.att[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));                                   // j = 0
+    ps.total[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));                                 // sample 0
+    ps.direct[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ps.accum[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     ps.statBox[slot] = 0;
     ps.statTri[slot] = 0;
     q.active[0][slot] = slot;
@@ -751,15 +727,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
 
     if (live) {
         slot = sa.inActive[gid];
-        rt_vec3 ro = ld3(ps.rayO, slot), rd = ld3(ps.rayD, slot);
-        rt_vec3 att = ld3(ps.att, slot), total = ld3(ps.total, slot), direct = ld3(ps.direct, slot);
-        float misW = ps.misW[slot];
-        uint32_t state = ps.rng[slot];
-        uint32_t jraw = ps.bounce[slot];
+        const float4 sO = ps.rayO[slot], sD = ps.rayD[slot], sA = ps.att[slot], sT = ps.total[slot], sDi = ps.direct[slot];
+        const float4 hM = ps.hit[RAY_MAIN][slot];
+        rt_vec3 ro = f4xyz(sO), rd = f4xyz(sD);
+        rt_vec3 att = f4xyz(sA), total = f4xyz(sT), direct = f4xyz(sDi);
+        float misW = sO.w;
+        uint32_t state = __float_as_uint(sD.w);
+        uint32_t jraw = __float_as_uint(sA.w);
+        uint32_t samplesDone = __float_as_uint(sT.w);
         uint32_t j = jraw & 0x7fffffffu;
         const bool pending = (jraw >> 31) != 0u;
 
-        const uint32_t obj = ps.hitObj[RAY_MAIN][slot];
+        const uint32_t obj = __float_as_uint(hM.y);
+        const uint32_t hitTriIdx = __float_as_uint(hM.z);
         refRays = 1;  // this segment's calculateIntersections (raytrace.comp:496)
 
         bool done = false;       // this sample's trace() returned
@@ -770,28 +750,30 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
                 // finish diffuseBRDF of the previous bounce (:443-460); its three
                 // scene queries were the NEE ray (once for :443 and :447) and the
                 // cosine probe (:453)
-                float tL = ps.hitT[RAY_NEE][slot], tC = ps.hitT[RAY_PROBE][slot];
-                uint32_t oL = ps.hitObj[RAY_NEE][slot], oC = ps.hitObj[RAY_PROBE][slot];
-                rt_vec3 dL = ld3(ps.auxDL, slot), dC = ld3(ps.auxDC, slot);
+                const float4 hL = ps.hit[RAY_NEE][slot], hC = ps.hit[RAY_PROBE][slot];
+                const float4 aO = ps.auxO[slot], aL = ps.auxDL[slot], aC = ps.auxDC[slot];
+                float tL = hL.x, tC = hC.x;
+                uint32_t oL = __float_as_uint(hL.y), oC = __float_as_uint(hC.y);
+                rt_vec3 dL = f4xyz(aL), dC = f4xyz(aC);
                 uint32_t lm = (oL == RT_HIT_NONE) ? 0u : hit_material(sc, oL);
                 float4 lmE = sc.mats[3 * lm + 1];
                 float realLightPDF = light_sample_pdf(sc, tL, oL, dL);
-                float cosinePDF = ps.pendCosPdfL[slot];
+                float cosinePDF = aL.w;
                 float misWeight1 = realLightPDF * realLightPDF / (realLightPDF * realLightPDF + cosinePDF * cosinePDF);
                 if (rt_isnan(misWeight1)) misWeight1 = 0.f;
                 float lightPDF = light_sample_pdf(sc, tC, oC, dC);
-                float realCosinePDF = ps.pendCosPdfC[slot];
+                float realCosinePDF = aC.w;
                 float misWeight2 = realCosinePDF * realCosinePDF / (lightPDF * lightPDF + realCosinePDF * realCosinePDF);
                 if (rt_isnan(misWeight2)) misWeight2 = 0.f;
-                rt_vec3 albedo = ld3(ps.pendAlbedo, slot);
+                rt_vec3 albedo = f4xyz(ps.pendAlbedo[slot]);
                 rt_vec3 dl = rt_scale(rt_v3(lmE.x, lmE.y, lmE.z), lmE.w);
                 float k = (realLightPDF == 0.f) ? 0.f : misWeight1 / realLightPDF;
-                rt_vec3 f = rt_scale(rt_scale(rt_scale(albedo, RT_INV_PI), ps.pendNDotL[slot]), k);
+                rt_vec3 f = rt_scale(rt_scale(rt_scale(albedo, RT_INV_PI), aO.w), k);
                 direct = rt_mul(dl, f);
                 misW = misWeight2;
             }
 
-            FullHit hit = reconstruct_hit(sc, ro, rd, obj, ps.hitTri[slot]);
+            FullHit hit = reconstruct_hit(sc, ro, rd, obj, hitTriIdx);
             float4 mA = sc.mats[3 * hit.materialIndex], mE = sc.mats[3 * hit.materialIndex + 1], mI = sc.mats[3 * hit.materialIndex + 2];
 
             // 0-1 NEE (:501-505)
@@ -852,13 +834,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
                     radiance = rt_v3(radiance.x / realCosinePDF, radiance.y / realCosinePDF, radiance.z / realCosinePDF);
                     sampledDir = cosineSample;
 
-                    st3(ps.auxO, slot, origin);
-                    st3(ps.auxDL, slot, lightSample);
-                    st3(ps.auxDC, slot, cosineSample);
-                    st3(ps.pendAlbedo, slot, albedo);
-                    ps.pendNDotL[slot] = rt_max(0.f, rt_dot(hit.normal, lightSample));
-                    ps.pendCosPdfL[slot] = rt_max(0.f, rt_dot(lightSample, hit.normal) * RT_INV_PI);
-                    ps.pendCosPdfC[slot] = realCosinePDF;
+                    ps.auxO[slot] = mk4(origin, rt_max(0.f, rt_dot(hit.normal, lightSample)));
+                    ps.auxDL[slot] = mk4(lightSample, rt_max(0.f, rt_dot(lightSample, hit.normal) * RT_INV_PI));
+                    ps.auxDC[slot] = mk4(cosineSample, realCosinePDF);
+                    ps.pendAlbedo[slot] = mk4(albedo, 0.f);
                 }
                 att = rt_mul(att, radiance);
 
@@ -886,16 +865,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
 
         if (done) {
             nPaths = 1;
-            rt_vec3 acc = ld3(ps.accum, slot);
+            float4 acc = ps.accum[slot];
             if (zeroed) total = rt_v3(0.f, 0.f, 0.f);
-            acc = rt_add(acc, total);
-            st3(ps.accum, slot, acc);
-            uint32_t s = ps.sample[slot] + 1;
-            ps.sample[slot] = s;
-            if (s < fp.samples) {
+            const rt_vec3 sum = rt_add(f4xyz(acc), total);
+            ps.accum[slot] = mk4(sum, 0.f);
+            samplesDone++;
+            if (samplesDone < fp.samples) {
                 // next sample of this pixel: same primary ray, RNG state runs on (:571-573)
-                uint32_t gx, gy;
-                uint32_t krow;
+                uint32_t gx, gy, krow;
                 slot_to_pixel(fp, slot, gx, gy, krow);
                 ro = rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]);
                 rd = primary_dir(fp, gx, gy);
@@ -912,15 +889,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
         }
 
         if (alive) {
-            st3(ps.rayO, slot, ro);
-            st3(ps.rayD, slot, rd);
-            st3(ps.att, slot, att);
-            st3(ps.total, slot, total);
-            st3(ps.direct, slot, direct);
-            ps.misW[slot] = misW;
-            ps.bounce[slot] = j | (wantAux ? 0x80000000u : 0u);
+            ps.rayO[slot] = mk4(ro, misW);
+            ps.rayD[slot] = mk4u(rd, state);
+            ps.att[slot] = mk4u(att, j | (wantAux ? 0x80000000u : 0u));
+            ps.total[slot] = mk4u(total, samplesDone);
+            ps.direct[slot] = mk4(direct, 0.f);
         }
-        ps.rng[slot] = state;
     }
 
     // wave-level compaction: one atomic per wave and queue, ranks from ballots
@@ -960,7 +934,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathState ps, FrameParams fp, float4* rgba) {
     uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (slot >= fp.nPixels) return;
-    rt_vec3 out = ld3(ps.accum, slot);
+    rt_vec3 out = f4xyz(ps.accum[slot]);
     float fs = (float)fp.samples;
     out = rt_v3(out.x / fs, out.y / fs, out.z / fs);
     float weight = 1.f / ((float)fp.frameCount + 1.f);
@@ -991,16 +965,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hit_details(DevScene sc, PathState
     if (i >= n) return;
     RtHit h;
     memset(&h, 0, sizeof(h));
-    h.dst = ps.hitT[RAY_MAIN][i];
-    uint32_t obj = ps.hitObj[RAY_MAIN][i];
+    const float4 hm = ps.hit[RAY_MAIN][i];
+    h.dst = hm.x;
+    uint32_t obj = __float_as_uint(hm.y);
+    const uint32_t tri = __float_as_uint(hm.z);
     h.boxTests = perRayBox[i];
     h.triTests = perRayTri[i];
     if (obj != RT_HIT_NONE) {
-        FullHit f = reconstruct_hit(sc, ld3(ps.rayO, i), ld3(ps.rayD, i), obj, ps.hitTri[i]);
+        FullHit f = reconstruct_hit(sc, f4xyz(ps.rayO[i]), f4xyz(ps.rayD[i]), obj, tri);
         h.didHit = 1;
         h.isSphere = (obj & RT_HIT_SPHERE) ? 1u : 0u;
         h.objectHitIndex = obj & ~RT_HIT_SPHERE;
-        h.triHitIndex = h.isSphere ? 0u : ps.hitTri[i];
+        h.triHitIndex = h.isSphere ? 0u : tri;
         h.materialIndex = f.materialIndex;
         h.frontFace = f.frontFace;
         h.hitPoint[0] = f.hitPoint.x; h.hitPoint[1] = f.hitPoint.y; h.hitPoint[2] = f.hitPoint.z;
