@@ -715,10 +715,12 @@ struct ShadeArgs {
 };
 
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, ShadeArgs sa, FrameParams fp) {
+    __shared__ uint32_t s_cnt[RT_BLOCK / RT_WAVE][5];  // per wave: alive, aux, refRays, paths, segments
+    __shared__ uint32_t s_base[2];
     const uint32_t n = *sa.inCount;
+    if (blockIdx.x * RT_BLOCK >= n) return;  // block-uniform
     const uint32_t gid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const bool live = gid < n;
-    if (__ballot(live) == 0ull) return;
 
     bool alive = false;    // path (or its successor sample) has a main ray for the next round
     bool wantAux = false;  // and two probe rays
@@ -897,34 +899,40 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
         }
     }
 
-    // wave-level compaction: one atomic per wave and queue, ranks from ballots
+    // Queue compaction: ranks inside a wave from ballots, wave offsets through LDS, and ONE atomic
+    // per block and queue (a single hot counter saturates near 90 atomics/us; per-wave atomics made
+    // this kernel wait on them for half of its run time).
     const unsigned long long mAlive = __ballot(alive);
     const unsigned long long mAux = __ballot(alive && wantAux);
     const uint32_t nAlive = __popcll(mAlive), nAux = __popcll(mAux);
-    uint32_t baseA = 0, baseR = 0;
-    if (lane_id() == 0 && nAlive) {
-        baseA = atomicAdd(sa.outActiveCount, nAlive);
-        baseR = atomicAdd(sa.outRayCount, nAlive + 2u * nAux);
+    const uint32_t wRef = wave_sum_u32(refRays), wPaths = wave_sum_u32(nPaths), wSeg = wave_sum_u32(live ? 1u : 0u);
+    const uint32_t wv = threadIdx.x / RT_WAVE;
+    if (lane_id() == 0) {
+        s_cnt[wv][0] = nAlive; s_cnt[wv][1] = nAux; s_cnt[wv][2] = wRef; s_cnt[wv][3] = wPaths; s_cnt[wv][4] = wSeg;
     }
-    baseA = __shfl(baseA, 0, RT_WAVE);
-    baseR = __shfl(baseR, 0, RT_WAVE);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tA = 0, tX = 0, tRef = 0, tP = 0, tS = 0;
+        for (int w = 0; w < RT_BLOCK / RT_WAVE; w++) { tA += s_cnt[w][0]; tX += s_cnt[w][1]; tRef += s_cnt[w][2]; tP += s_cnt[w][3]; tS += s_cnt[w][4]; }
+        s_base[0] = tA ? atomicAdd(sa.outActiveCount, tA) : 0u;
+        s_base[1] = tA ? atomicAdd(sa.outRayCount, tA + 2u * tX) : 0u;
+        atomicAdd(&sa.counters->raysReference, (unsigned long long)tRef);
+        atomicAdd(&sa.counters->paths, (unsigned long long)tP);
+        atomicAdd(&sa.counters->segments, (unsigned long long)tS);
+    }
+    __syncthreads();
     if (alive) {
-        uint32_t rk = lanes_below(mAlive);
+        uint32_t baseA = s_base[0], baseR = s_base[1];
+        for (uint32_t w = 0; w < wv; w++) { baseA += s_cnt[w][0]; baseR += s_cnt[w][0] + 2u * s_cnt[w][1]; }
+        const uint32_t rk = lanes_below(mAlive);
         sa.outActive[baseA + rk] = slot;
-        // main rays first, then the NEE rays, then the cosine probes of this wave
+        // per wave: main rays first, then its NEE rays, then its cosine probes
         sa.outRays[baseR + rk] = (slot << 2) | RAY_MAIN;
         if (wantAux) {
-            uint32_t ra = lanes_below(mAux);
+            const uint32_t ra = lanes_below(mAux);
             sa.outRays[baseR + nAlive + ra] = (slot << 2) | RAY_NEE;
             sa.outRays[baseR + nAlive + nAux + ra] = (slot << 2) | RAY_PROBE;
         }
-    }
-
-    uint32_t wRef = wave_sum_u32(refRays), wPaths = wave_sum_u32(nPaths), wSeg = wave_sum_u32(live ? 1u : 0u);
-    if (lane_id() == 0) {
-        atomicAdd(&sa.counters->raysReference, (unsigned long long)wRef);
-        atomicAdd(&sa.counters->paths, (unsigned long long)wPaths);
-        atomicAdd(&sa.counters->segments, (unsigned long long)wSeg);
     }
 }
 
