@@ -62,6 +62,7 @@ struct rt_ctx {
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
     int refill = 16;        // k_trace_pw: idle lanes that trigger a refill
     int chunk = 256;        // k_trace_pw: most queue entries reserved per atomic
+    int fastLanes = 24;     // k_trace_pw: lanes at interior nodes that skip the full vote
     int wSetup = 16, wLeaf = 8; // k_trace_pw: vote weights in eighths (interior = 8)
     int blocksPerCU = 0;    // k_trace_pw: 0 = occupancy query
     int numCUs = 256;
@@ -168,7 +169,7 @@ void launch_trace_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     }
     uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
     uint32_t blocks = std::min((maxRays + RT_BLOCK - 1) / RT_BLOCK, resident);
-    TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refill, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf,
+    TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refill, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes,
                    ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters))};
     // per-ray counters are only needed for the pixel heat maps (debug >= 0) and rt_trace_rays
     const bool pix = c->pixStats || ta.perRayBox;
@@ -686,6 +687,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     std::string k(key);
     if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
     else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; }
+    else if (k == "fast_lanes") { if (value < 1 || value > 65) return c->fail("fast_lanes: 1..65"); c->fastLanes = value; }
     else if (k == "chunk") { if (value < 1 || value > 4096) return c->fail("chunk: 1..4096"); c->chunk = value; }
     else if (k == "w_setup") { if (value < 1 || value > 512) return c->fail("w_setup: 1..512"); c->wSetup = value; }
     else if (k == "w_leaf") { if (value < 1 || value > 512) return c->fail("w_leaf: 1..512"); c->wLeaf = value; }

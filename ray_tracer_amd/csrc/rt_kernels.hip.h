@@ -355,6 +355,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
 #define RT_CUR_SETUP 0xfffffffdu  // entering object `obj`, which has a general transform
 #define RT_CUR_WORLD 0xfffffffcu  // back to the world-space ray after a general-transform object
 #define RT_CUR_INIT 0xfffffffbu   // new ray: load it, sphere tests, 1/dir
+#define RT_CUR_DONE 0xfffffffau   // ray finished: store the result
 #define RT_CUR_LEAF_MAX 0xfffffff0u  // leaf references are below the markers
 
 struct TracePwArgs {
@@ -364,16 +365,24 @@ struct TracePwArgs {
     uint32_t refill;          // re-arm idle lanes when at least this many are idle
     uint32_t chunk;           // most queue entries a wave reserves per atomic (guided: fewer near the end)
     uint32_t wSetup, wLeaf;   // vote weights in eighths (interior = 8)
+    uint32_t fastLanes;       // go straight to the interior step when at least this many lanes are at interior nodes
     uint32_t* perRayBox;      // PIX only
     uint32_t* perRayTri;
     DevCounters* counters;
     unsigned long long* phaseStats;  // STATS only: [8] rounds and active lanes per phase
 };
 
+// Instruction issue, scalar and vector alike, is what bounds this kernel (measured: ~110 VALU +
+// ~100 SALU + 16 branches per round kept both issue ports ~70 % busy while the L1 and L2 idled;
+// serving half of the node fetches from LDS changed nothing). So the hot round is written with as
+// little control flow as possible: one ballot decides "enough lanes are at an interior node" and
+// goes straight to the interior step; pushes and pops are unconditional LDS accesses with
+// predicated pointer updates; the full vote, the refill and the leaf / setup steps live on a slow
+// path that is only entered when fewer than `fastLanes` lanes are at interior nodes.
 template <int STACK, bool PIX, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
-    __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * STACK * RT_WAVE];
-    uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * STACK * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
+    __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];  // +1: pushes are unconditional
+    uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
     const uint32_t n = *ta.count;
 
     uint32_t cur = RT_CUR_IDLE;
@@ -400,55 +409,126 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
     };
 
     for (;;) {
-        // ---------------- refill: hand queue entries to idle lanes (the ray itself is loaded by the setup step).
-        // The wave reserves `chunk` entries per atomic (one hot counter saturates near 90 atomics/us) and
-        // deals them out locally.
-        const unsigned long long mIdle = __ballot(cur == RT_CUR_IDLE);
-        const uint32_t nIdle = __popcll(mIdle);
-        if (nIdle == RT_WAVE && exhausted && resCount == 0) break;
-        if (nIdle >= ta.refill && (resCount || !exhausted)) {
-            if (resCount == 0) {
-                uint32_t base = 0;
-                if (lane_id() == 0) base = atomicAdd(ta.head, nextChunk);
-                base = __shfl(base, 0, RT_WAVE);
-                resBase = base;
-                resCount = base < n ? min(nextChunk, n - base) : 0u;
-                if (base + nextChunk >= n) exhausted = true;
-                // guided self-scheduling: big reservations while the queue is long, small ones near its end
-                const uint32_t left = base + nextChunk < n ? n - base - nextChunk : 0u;
-                nextChunk = min(ta.chunk, max(16u, left / (2u * gridDim.x * (RT_BLOCK / RT_WAVE))));
+        const unsigned long long mI = __ballot((int32_t)cur >= 0);
+        uint32_t nI = __popcll(mI);
+        bool runI = nI >= ta.fastLanes;
+        if (!runI) {
+            // ================= slow path: refill, full vote, leaf and setup steps =================
+            // refill: hand queue entries to idle lanes (the ray itself is loaded by the setup step). The wave
+            // reserves up to `chunk` entries per atomic (one hot counter saturates near 90 atomics/us) and
+            // deals them out locally; reservations shrink near the end of the queue (guided scheduling).
+            const unsigned long long mIdle = __ballot(cur == RT_CUR_IDLE);
+            const uint32_t nIdle = __popcll(mIdle);
+            if (nIdle == RT_WAVE && exhausted && resCount == 0) break;
+            if (nIdle >= ta.refill && (resCount || !exhausted)) {
+                if (resCount == 0) {
+                    uint32_t base = 0;
+                    if (lane_id() == 0) base = atomicAdd(ta.head, nextChunk);
+                    base = __shfl(base, 0, RT_WAVE);
+                    resBase = base;
+                    resCount = base < n ? min(nextChunk, n - base) : 0u;
+                    if (base + nextChunk >= n) exhausted = true;
+                    const uint32_t left = base + nextChunk < n ? n - base - nextChunk : 0u;
+                    nextChunk = min(ta.chunk, max(16u, left / (2u * gridDim.x * (RT_BLOCK / RT_WAVE))));
+                }
+                const uint32_t take = min(nIdle, resCount);
+                if (STATS) { dbgRounds[0]++; dbgLanes[0] += take; }
+                if (cur == RT_CUR_IDLE) {
+                    const uint32_t rk = lanes_below(mIdle);
+                    if (rk < take) {
+                        qidx = resBase + rk;
+                        id = ta.queue ? ta.queue[qidx] : (qidx << 2);
+                        cur = RT_CUR_INIT;
+                    }
+                }
+                resBase += take;
+                resCount -= take;
             }
-            const uint32_t take = min(nIdle, resCount);
-            if (STATS) { dbgRounds[0]++; dbgLanes[0] += take; }
-            if (cur == RT_CUR_IDLE) {
-                const uint32_t rk = lanes_below(mIdle);
-                if (rk < take) {
-                    qidx = resBase + rk;
-                    id = ta.queue ? ta.queue[qidx] : (qidx << 2);
-                    cur = RT_CUR_INIT;
+
+            // vote (weighted: a step that feeds lanes back into the interior state may run with fewer lanes)
+            const uint32_t nL = __popcll(__ballot((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX));
+            const uint32_t nS = __popcll(__ballot(cur - RT_CUR_INIT <= RT_CUR_SETUP - RT_CUR_INIT));
+            const uint32_t scS = nS * ta.wSetup, scI = nI * 8u, scL = nL * ta.wLeaf;
+            runI = nI && scI >= scL && scI >= scS;
+            const bool runL = !runI && nL && scL >= scS;
+            const bool runS = !runI && !runL && nS;
+            if (STATS) {
+                if (runL) { dbgRounds[3]++; dbgLanes[3] += nL; }
+                else if (runS) { dbgRounds[1]++; dbgLanes[1] += nS; }
+            }
+
+            if (runL) {
+                // ---------------- leaf step: one triangle (all of them for a leaf with > 7)
+                if ((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX) {
+                    const uint32_t cnt = (cur >> RT_LEAF_CNT_SHIFT) & 7u;
+                    uint32_t j = cur & RT_LEAF_IDX_MASK, jEnd;
+                    if (cnt == 0) {  // j is the node
+                        jEnd = __float_as_uint(sc.nodes[2 * (size_t)j + 1].w);
+                        j = sc.leafFirst[j];
+                        jEnd += j;
+                        cur = RT_CUR_NEED;
+                    } else {
+                        jEnd = j + 1;
+                        cur = (cnt > 1u) ? (cur + 1u - (1u << RT_LEAF_CNT_SHIFT)) : RT_CUR_NEED;
+                    }
+                    if (PIX) rayTri += jEnd - j; else totTri += jEnd - j;
+                    for (; j < jEnd; j++) {
+                        const float4 a = sc.triPos[3 * (size_t)j], b = sc.triPos[3 * (size_t)j + 1], c = sc.triPos[3 * (size_t)j + 2];
+                        const TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
+                        if (h.didHit && h.dst < best) { best = h.dst; bestObj = obj - 1; bestTri = j; }
+                    }
+                }
+            } else if (runS) {
+                // ---------------- setup step: the only place that writes tro/trd/inv
+                //   INIT : new ray (world space, sphere tests)      -> NEED
+                //   WORLD: world-space ray again                     -> NEED
+                //   SETUP: into object `obj` with a general matrix   -> its root
+                if (cur - RT_CUR_INIT <= RT_CUR_SETUP - RT_CUR_INIT) {
+                    const uint32_t slot = id >> 2, kind = id & 3u;
+                    rt_vec3 wo, wd;
+                    if (kind == RAY_MAIN) { wo = f4xyz(ps.rayO[slot]); wd = f4xyz(ps.rayD[slot]); }
+                    else { wo = f4xyz(ps.auxO[slot]); wd = f4xyz(kind == RAY_NEE ? ps.auxDL[slot] : ps.auxDC[slot]); }
+                    if (cur == RT_CUR_INIT) {
+                        best = RT_MISS_DST; bestObj = RT_HIT_NONE; bestTri = 0;
+                        for (uint32_t i = 0; i < sc.sphereCount; i++) {
+                            SphereHit h = sphere_intersect(sc.spheres[i], wo, wd);
+                            if (h.didHit && h.dst < best) { best = h.dst; bestObj = RT_HIT_SPHERE | i; }
+                        }
+                        // finite and non-zero direction, finite origin without negative zeros
+                        const uint32_t E = 0x7f800000u, M = 0x7fffffffu;
+                        plain = ((rt_f2u(wd.x) & M) - 1u < E - 1u) && ((rt_f2u(wd.y) & M) - 1u < E - 1u) && ((rt_f2u(wd.z) & M) - 1u < E - 1u) &&
+                                ((rt_f2u(wo.x) & M) < E) && ((rt_f2u(wo.y) & M) < E) && ((rt_f2u(wo.z) & M) < E) &&
+                                rt_f2u(wo.x) != 0x80000000u && rt_f2u(wo.y) != 0x80000000u && rt_f2u(wo.z) != 0x80000000u;
+                        obj = 0; sp = 0;
+                        if (PIX) { rayBox = 0; rayTri = 0; }
+                        totRays++;
+                        fetch_next_meta();
+                    }
+                    const bool general = cur == RT_CUR_SETUP;
+                    if (general) {
+                        const float4 r0 = sc.objInv[3 * obj], r1 = sc.objInv[3 * obj + 1], r2 = sc.objInv[3 * obj + 2];
+                        trd = xform_dir_rows(r0, r1, r2, wd);
+                        tro = xform_point_rows(r0, r1, r2, wo);
+                    } else {
+                        trd = wd;
+                        tro = wo;
+                    }
+                    inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
+                    atWorld = !general;
+                    if (general) {
+                        cur = nxW;
+                        obj++;
+                        fetch_next_meta();
+                    } else {
+                        cur = RT_CUR_NEED;
+                    }
                 }
             }
-            resBase += take;
-            resCount -= take;
-        }
-
-        // ---------------- vote
-        const uint32_t nI = __popcll(__ballot((int32_t)cur >= 0));
-        const uint32_t nL = __popcll(__ballot((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX));
-        const uint32_t nS = __popcll(__ballot(cur - RT_CUR_INIT <= RT_CUR_SETUP - RT_CUR_INIT));
-        // weighted: a step that feeds lanes back into the interior state may run with fewer lanes
-        const uint32_t scS = nS * ta.wSetup, scI = nI * 8u, scL = nL * ta.wLeaf;
-        const bool runI = nI && scI >= scL && scI >= scS;
-        const bool runL = !runI && nL && scL >= scS;
-        const bool runS = !runI && !runL && nS;
-        if (STATS) {
-            if (runI) { dbgRounds[2]++; dbgLanes[2] += nI; }
-            else if (runL) { dbgRounds[3]++; dbgLanes[3] += nL; }
-            else if (runS) { dbgRounds[1]++; dbgLanes[1] += nS; }
         }
 
         if (runI) {
-            // ---------------- interior step: both children of the pair `cur`
+            // ================= interior step: both children of the pair `cur` =================
+            if (STATS) { dbgRounds[2]++; dbgLanes[2] += nI; }
             if ((int32_t)cur >= 0) {
                 const float4* pr = sc.nodes + 2 * (size_t)cur;
                 const float4 lo1 = pr[0], hi1 = pr[1], lo2 = pr[2], hi2 = pr[3];
@@ -458,97 +538,28 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
                 const bool nearA = d1 <= d2;
                 const float dNear = nearA ? d1 : d2, dFar = nearA ? d2 : d1;
                 const uint32_t nW = __float_as_uint(nearA ? lo1.w : lo2.w), fW = __float_as_uint(nearA ? lo2.w : lo1.w);
-                if (dFar < best) {  // ready-made word: pair index or leaf reference
-                    stack[sp * RT_WAVE] = fW;
-                    sp++;
-                }
+                stack[sp * RT_WAVE] = fW;          // ready-made word (pair index or leaf reference); kept only if it qualifies
+                sp += (dFar < best) ? 1u : 0u;
                 cur = (dNear < best) ? nW : RT_CUR_NEED;
-            }
-        } else if (runL) {
-            // ---------------- leaf step: one triangle (all of them for a leaf with > 7)
-            if ((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX) {
-                const uint32_t cnt = (cur >> RT_LEAF_CNT_SHIFT) & 7u;
-                uint32_t j = cur & RT_LEAF_IDX_MASK, jEnd;
-                if (cnt == 0) {  // j is the node
-                    jEnd = __float_as_uint(sc.nodes[2 * (size_t)j + 1].w);
-                    j = sc.leafFirst[j];
-                    jEnd += j;
-                    cur = RT_CUR_NEED;
-                } else {
-                    jEnd = j + 1;
-                    cur = (cnt > 1u) ? (cur + 1u - (1u << RT_LEAF_CNT_SHIFT)) : RT_CUR_NEED;
-                }
-                if (PIX) rayTri += jEnd - j; else totTri += jEnd - j;
-                for (; j < jEnd; j++) {
-                    const float4 a = sc.triPos[3 * (size_t)j], b = sc.triPos[3 * (size_t)j + 1], c = sc.triPos[3 * (size_t)j + 2];
-                    const TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
-                    if (h.didHit && h.dst < best) { best = h.dst; bestObj = obj - 1; bestTri = j; }
-                }
-            }
-        } else if (runS) {
-            // ---------------- setup step: the only place that writes tro/trd/inv
-            //   INIT : new ray (world space, sphere tests)      -> NEED
-            //   WORLD: world-space ray again                     -> NEED
-            //   SETUP: into object `obj` with a general matrix   -> its root
-            if (cur - RT_CUR_INIT <= RT_CUR_SETUP - RT_CUR_INIT) {
-                const uint32_t slot = id >> 2, kind = id & 3u;
-                rt_vec3 wo, wd;
-                if (kind == RAY_MAIN) { wo = f4xyz(ps.rayO[slot]); wd = f4xyz(ps.rayD[slot]); }
-                else { wo = f4xyz(ps.auxO[slot]); wd = f4xyz(kind == RAY_NEE ? ps.auxDL[slot] : ps.auxDC[slot]); }
-                if (cur == RT_CUR_INIT) {
-                    best = RT_MISS_DST; bestObj = RT_HIT_NONE; bestTri = 0;
-                    for (uint32_t i = 0; i < sc.sphereCount; i++) {
-                        SphereHit h = sphere_intersect(sc.spheres[i], wo, wd);
-                        if (h.didHit && h.dst < best) { best = h.dst; bestObj = RT_HIT_SPHERE | i; }
-                    }
-                    // finite and non-zero direction, finite origin without negative zeros
-                    const uint32_t E = 0x7f800000u, M = 0x7fffffffu;
-                    plain = ((rt_f2u(wd.x) & M) - 1u < E - 1u) && ((rt_f2u(wd.y) & M) - 1u < E - 1u) && ((rt_f2u(wd.z) & M) - 1u < E - 1u) &&
-                            ((rt_f2u(wo.x) & M) < E) && ((rt_f2u(wo.y) & M) < E) && ((rt_f2u(wo.z) & M) < E) &&
-                            rt_f2u(wo.x) != 0x80000000u && rt_f2u(wo.y) != 0x80000000u && rt_f2u(wo.z) != 0x80000000u;
-                    obj = 0; sp = 0;
-                    if (PIX) { rayBox = 0; rayTri = 0; }
-                    totRays++;
-                    fetch_next_meta();
-                }
-                const bool general = cur == RT_CUR_SETUP;
-                if (general) {
-                    const float4 r0 = sc.objInv[3 * obj], r1 = sc.objInv[3 * obj + 1], r2 = sc.objInv[3 * obj + 2];
-                    trd = xform_dir_rows(r0, r1, r2, wd);
-                    tro = xform_point_rows(r0, r1, r2, wo);
-                } else {
-                    trd = wd;
-                    tro = wo;
-                }
-                inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
-                atWorld = !general;
-                if (general) {
-                    cur = nxW;
-                    obj++;
-                    fetch_next_meta();
-                } else {
-                    cur = RT_CUR_NEED;
-                }
             }
         }
 
-        // ---------------- tail: next node for every lane that ran out of work
-        if (cur == RT_CUR_NEED) {
-            if (sp > 0) {
-                cur = stack[(--sp) * RT_WAVE];
-            } else if (obj < sc.objectCount) {
-                if ((nxFlags & 1u) && plain) {  // identity transform: register moves only
-                    if (atWorld) {
-                        cur = nxW;
-                        obj++;
-                        fetch_next_meta();
-                    } else {
-                        cur = RT_CUR_WORLD;
-                    }
-                } else {
-                    cur = RT_CUR_SETUP;
-                }
-            } else {
+        // ================= tail: next node for every lane that ran out of work (predicated) =================
+        {
+            const bool need = cur == RT_CUR_NEED;
+            const bool has = sp > 0;
+            const uint32_t top = stack[((has ? sp : 1u) - 1u) * RT_WAVE];
+            const bool objLeft = obj < sc.objectCount;
+            const bool ident = (nxFlags & 1u) && plain;  // identity transform: register moves only
+            const uint32_t whenEmpty = objLeft ? (ident ? (atWorld ? nxW : RT_CUR_WORLD) : RT_CUR_SETUP) : RT_CUR_DONE;
+            const bool enter = need && !has && objLeft && ident && atWorld;
+            cur = need ? (has ? top : whenEmpty) : cur;
+            sp -= (need && has) ? 1u : 0u;
+            if (enter) {
+                obj++;
+                fetch_next_meta();
+            }
+            if (cur == RT_CUR_DONE) {
                 const uint32_t slot = id >> 2, kind = id & 3u;
                 ps.hit[kind][slot] = make_float4(best, __uint_as_float(bestObj), __uint_as_float(bestTri), 0.f);
                 if (PIX && kind == RAY_MAIN) { ps.statBox[slot] += rayBox; ps.statTri[slot] += rayTri; }
