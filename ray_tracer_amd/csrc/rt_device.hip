@@ -60,10 +60,10 @@ struct rt_ctx {
 
     // tuning (rt_set_tuning)
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
-    int refill = 16;        // k_trace_pw: idle lanes that trigger a refill
+    int refill = 8;         // k_trace_pw: idle lanes that trigger a refill
     int chunk = 256;        // k_trace_pw: most queue entries reserved per atomic
     int fastLanes = 24;     // k_trace_pw: lanes at interior nodes that skip the full vote
-    int wSetup = 16, wLeaf = 8; // k_trace_pw: vote weights in eighths (interior = 8)
+    int wSetup = 32, wLeaf = 8; // k_trace_pw: vote weights in eighths (interior = 8)
     int blocksPerCU = 0;    // k_trace_pw: 0 = occupancy query
     int numCUs = 256;
     int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase
@@ -535,7 +535,7 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     DevCounters* dc = (DevCounters*)c->counterBuf.p;
     uint32_t* counts = c->q.counts;
 
-    hipLaunchKernelGGL(k_raygen, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->ps, c->q, fp);
+    hipLaunchKernelGGL(k_raygen, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, c->q, fp);
     RT_HIP(c, hipGetLastError());
 
     if (fp.samples > 0) {
@@ -627,6 +627,7 @@ int rt_trace_rays(rt_ctx* c, uint32_t n, const float* origins, const float* dirs
     RT_HIP(c, hipMemcpyAsync(c->q.counts, c->hostCounts, 20, hipMemcpyHostToDevice, c->stream));
     RT_HIP(c, hipMemsetAsync(c->ps.statBox, 0, (size_t)n * 4, c->stream));
     RT_HIP(c, hipMemsetAsync(c->ps.statTri, 0, (size_t)n * 4, c->stream));
+    hipLaunchKernelGGL(k_seed_rays, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, n);
     TraceArgs ta{nullptr, c->q.counts, prb, prt, (DevCounters*)c->counterBuf.p};
     if ((rc = launch_trace(c, n, ta))) return rc;
     hipLaunchKernelGGL(k_hit_details, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, n, prb, prt, dh);

@@ -168,6 +168,19 @@ __device__ __forceinline__ SphereHit sphere_intersect(float4 s, rt_vec3 ro, rt_v
     return h;
 }
 
+// The sphere loop of calculateIntersections (raytrace.comp:282-287) for one ray. The kernels that
+// CREATE rays (k_raygen, k_shade) run it, with all lanes busy, and leave the result in the ray's hit
+// record as the starting "closest hit" of the traversal; k_trace_pw then only walks the objects.
+__device__ __forceinline__ float4 sphere_seed(const DevScene& sc, rt_vec3 ro, rt_vec3 rd) {
+    float best = RT_MISS_DST;
+    uint32_t obj = RT_HIT_NONE;
+    for (uint32_t i = 0; i < sc.sphereCount; i++) {
+        SphereHit h = sphere_intersect(sc.spheres[i], ro, rd);
+        if (h.didHit && h.dst < best) { best = h.dst; obj = RT_HIT_SPHERE | i; }
+    }
+    return make_float4(best, __uint_as_float(obj), __uint_as_float(0u), 0.f);
+}
+
 struct TriHit { bool didHit, frontFace; float dst, u, v, w; };
 
 // raytrace.comp:227-247
@@ -489,11 +502,9 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
                     if (kind == RAY_MAIN) { wo = f4xyz(ps.rayO[slot]); wd = f4xyz(ps.rayD[slot]); }
                     else { wo = f4xyz(ps.auxO[slot]); wd = f4xyz(kind == RAY_NEE ? ps.auxDL[slot] : ps.auxDC[slot]); }
                     if (cur == RT_CUR_INIT) {
-                        best = RT_MISS_DST; bestObj = RT_HIT_NONE; bestTri = 0;
-                        for (uint32_t i = 0; i < sc.sphereCount; i++) {
-                            SphereHit h = sphere_intersect(sc.spheres[i], wo, wd);
-                            if (h.didHit && h.dst < best) { best = h.dst; bestObj = RT_HIT_SPHERE | i; }
-                        }
+                        // the ray's creator already ran the sphere loop (sphere_seed)
+                        const float4 seed = ps.hit[kind][slot];
+                        best = seed.x; bestObj = __float_as_uint(seed.y); bestTri = 0;
                         // finite and non-zero direction, finite origin without negative zeros
                         const uint32_t E = 0x7f800000u, M = 0x7fffffffu;
                         plain = ((rt_f2u(wd.x) & M) - 1u < E - 1u) && ((rt_f2u(wd.y) & M) - 1u < E - 1u) && ((rt_f2u(wd.z) & M) - 1u < E - 1u) &&
@@ -696,14 +707,16 @@ __device__ __forceinline__ void slot_to_pixel(const FrameParams& fp, uint32_t sl
 }
 
 // ---------------------------------------------------------------- k_raygen
-__global__ __launch_bounds__(RT_BLOCK) void k_raygen(PathState ps, Queues q, FrameParams fp) {
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(DevScene sc, PathState ps, Queues q, FrameParams fp) {
     uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (slot >= fp.nPixels) return;
     uint32_t gx, gy;
     uint32_t krow;
     slot_to_pixel(fp, slot, gx, gy, krow);
     ps.rayO[slot] = make_float4(fp.camPos[0], fp.camPos[1], fp.camPos[2], 1.f);                          // misWeight = 1
-    ps.rayD[slot] = mk4u(primary_dir(fp, gx, gy), gy * fp.width + gx + fp.startingSeed);              // RNG seed (:564)
+    const rt_vec3 pd = primary_dir(fp, gx, gy);
+    ps.rayD[slot] = mk4u(pd, gy * fp.width + gx + fp.startingSeed);                                   // RNG seed (:564)
+    ps.hit[RAY_MAIN][slot] = sphere_seed(sc, rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]), pd);
     ps.att[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));                                   // j = 0
     ps.total[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));                                 // sample 0
     ps.direct[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -733,6 +746,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
     const uint32_t gid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const bool live = gid < n;
 
+    rt_vec3 auxOrigin = rt_v3(0, 0, 0), auxL = auxOrigin, auxC = auxOrigin;  // probe rays of this bounce (diffuse only)
     bool alive = false;    // path (or its successor sample) has a main ray for the next round
     bool wantAux = false;  // and two probe rays
     uint32_t slot = 0;
@@ -847,6 +861,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
                     radiance = rt_v3(radiance.x / realCosinePDF, radiance.y / realCosinePDF, radiance.z / realCosinePDF);
                     sampledDir = cosineSample;
 
+                    auxOrigin = origin; auxL = lightSample; auxC = cosineSample;
                     ps.auxO[slot] = mk4(origin, rt_max(0.f, rt_dot(hit.normal, lightSample)));
                     ps.auxDL[slot] = mk4(lightSample, rt_max(0.f, rt_dot(lightSample, hit.normal) * RT_INV_PI));
                     ps.auxDC[slot] = mk4(cosineSample, realCosinePDF);
@@ -902,6 +917,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
         }
 
         if (alive) {
+            ps.hit[RAY_MAIN][slot] = sphere_seed(sc, ro, rd);
+            if (wantAux) {
+                ps.hit[RAY_NEE][slot] = sphere_seed(sc, auxOrigin, auxL);
+                ps.hit[RAY_PROBE][slot] = sphere_seed(sc, auxOrigin, auxC);
+            }
             ps.rayO[slot] = mk4(ro, misW);
             ps.rayD[slot] = mk4u(rd, state);
             ps.att[slot] = mk4u(att, j | (wantAux ? 0x80000000u : 0u));
@@ -1002,6 +1022,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hit_details(DevScene sc, PathState
         h.normal[0] = f.normal.x; h.normal[1] = f.normal.y; h.normal[2] = f.normal.z;
     }
     out[i] = h;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_seed_rays(DevScene sc, PathState ps, uint32_t n) {
+    uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i < n) ps.hit[RAY_MAIN][i] = sphere_seed(sc, f4xyz(ps.rayO[i]), f4xyz(ps.rayD[i]));
 }
 
 // ---------------------------------------------------------------- misc kernels
