@@ -42,7 +42,7 @@ struct rt_ctx {
     std::vector<RootInfo> rootOf;             // per reference node; idx = ~0u unless a mesh root
 
     // path state
-    DevBuf stateBuf, queueBuf, fbBuf, counterBuf, scratchBuf;
+    DevBuf stateBuf, queueBuf, fbBuf, counterBuf, scratchBuf, overflowBuf;
     uint32_t capacity = 0;  // pixels the state buffers hold
     PathState ps{};
     Queues q{};
@@ -62,6 +62,7 @@ struct rt_ctx {
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
     int refill = 8;         // k_trace_pw: idle lanes that trigger a refill
     int chunk = 256;        // k_trace_pw: most queue entries reserved per atomic
+    int ldsStackCap = 24;   // k_trace_pw: LDS stack entries per lane (16 or 24); deeper BVHs use the overflow buffer
     int fastLanes = 24;     // k_trace_pw: lanes at interior nodes that skip the full vote
     int wSetup = 32, wLeaf = 8; // k_trace_pw: vote weights in eighths (interior = 8)
     int blocksPerCU = 0;    // k_trace_pw: 0 = occupancy query
@@ -156,26 +157,35 @@ int ensure_state(rt_ctx* c, uint32_t nPixels) {
     return 0;
 }
 
-template <int STACK>
-void launch_trace_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
-    if (c->traceVariant == 0) {
-        uint32_t blocks = (maxRays + RT_BLOCK - 1) / RT_BLOCK;
-        hipLaunchKernelGGL((k_trace<STACK>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, ta);
-        return;
-    }
+template <int STACK, bool OVF>
+int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     int perCU = c->blocksPerCU;
     if (perCU <= 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, false, false>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
     }
     uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
     uint32_t blocks = std::min((maxRays + RT_BLOCK - 1) / RT_BLOCK, resident);
+    uint32_t* overflow = nullptr;
+    if (OVF) {
+        const size_t need = (size_t)(c->maxLeafDepth - STACK) * resident * RT_BLOCK * 4;
+        int rc = dev_alloc(c, c->overflowBuf, need);
+        if (rc) return rc;
+        overflow = (uint32_t*)c->overflowBuf.p;
+    }
     TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refill, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes,
-                   ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters))};
+                   ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), overflow};
     // per-ray counters are only needed for the pixel heat maps (debug >= 0) and rt_trace_rays
     const bool pix = c->pixStats || ta.perRayBox;
-    if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, true, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
-    else if (pix) hipLaunchKernelGGL((k_trace_pw<STACK, true, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
-    else hipLaunchKernelGGL((k_trace_pw<STACK, false, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    else if (pix) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    else hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    return 0;
+}
+
+template <int STACK>
+void launch_v0_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
+    uint32_t blocks = (maxRays + RT_BLOCK - 1) / RT_BLOCK;
+    hipLaunchKernelGGL((k_trace<STACK>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, ta);
 }
 
 // the work counter (counts[4]) must be zero when this is called
@@ -193,12 +203,23 @@ int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
         RT_HIP(c, hipEventRecord(ev->a, c->stream));
     }
     const uint32_t d = c->maxLeafDepth;
-    if (d <= 8) launch_trace_t<8>(c, maxRays, ta);
-    else if (d <= 16) launch_trace_t<16>(c, maxRays, ta);
-    else if (d <= 24) launch_trace_t<24>(c, maxRays, ta);
-    else if (d <= 32) launch_trace_t<32>(c, maxRays, ta);
-    else if (d <= 48) launch_trace_t<48>(c, maxRays, ta);
-    else launch_trace_t<64>(c, maxRays, ta);
+    int rc = 0;
+    if (c->traceVariant == 0) {  // one ray per lane, whole stack in LDS
+        if (d <= 8) launch_v0_t<8>(c, maxRays, ta);
+        else if (d <= 16) launch_v0_t<16>(c, maxRays, ta);
+        else if (d <= 24) launch_v0_t<24>(c, maxRays, ta);
+        else if (d <= 32) launch_v0_t<32>(c, maxRays, ta);
+        else if (d <= 48) launch_v0_t<48>(c, maxRays, ta);
+        else launch_v0_t<64>(c, maxRays, ta);
+    } else {  // persistent waves; at most 24 entries in LDS, deeper ones in the overflow buffer
+        const uint32_t cap = (uint32_t)c->ldsStackCap;
+        if (d <= 8) rc = launch_pw_t<8, false>(c, maxRays, ta);
+        else if (d <= 16) rc = launch_pw_t<16, false>(c, maxRays, ta);
+        else if (d <= 24 && cap >= 24) rc = launch_pw_t<24, false>(c, maxRays, ta);
+        else if (cap >= 24) rc = launch_pw_t<24, true>(c, maxRays, ta);
+        else rc = launch_pw_t<16, true>(c, maxRays, ta);
+    }
+    if (rc) return rc;
     RT_HIP(c, hipGetLastError());
     if (ev) RT_HIP(c, hipEventRecord(ev->b, c->stream));
     c->traceLaunchesTotal++;
@@ -257,7 +278,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->sceneBufs) dev_free(b);
     for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->stateBuf,
-                      &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf})
+                      &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf})
         dev_free(*b);
     for (auto& e : c->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->hostCounts) (void)hipHostFree(c->hostCounts);
@@ -688,6 +709,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     std::string k(key);
     if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
     else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; }
+    else if (k == "lds_stack") { if (value != 16 && value != 24) return c->fail("lds_stack: 16 or 24"); c->ldsStackCap = value; }
     else if (k == "fast_lanes") { if (value < 1 || value > 65) return c->fail("fast_lanes: 1..65"); c->fastLanes = value; }
     else if (k == "chunk") { if (value < 1 || value > 4096) return c->fail("chunk: 1..4096"); c->chunk = value; }
     else if (k == "w_setup") { if (value < 1 || value > 512) return c->fail("w_setup: 1..512"); c->wSetup = value; }

@@ -383,6 +383,7 @@ struct TracePwArgs {
     uint32_t* perRayTri;
     DevCounters* counters;
     unsigned long long* phaseStats;  // STATS only: [8] rounds and active lanes per phase
+    uint32_t* overflow;       // OVF only: stack entries beyond STACK, (maxDepth - STACK) x resident lanes
 };
 
 // Instruction issue, scalar and vector alike, is what bounds this kernel (measured: ~110 VALU +
@@ -392,11 +393,16 @@ struct TracePwArgs {
 // goes straight to the interior step; pushes and pops are unconditional LDS accesses with
 // predicated pointer updates; the full vote, the refill and the leaf / setup steps live on a slow
 // path that is only entered when fewer than `fastLanes` lanes are at interior nodes.
-template <int STACK, bool PIX, bool STATS>
+// OVF: the BVH is deeper than STACK; entries beyond the LDS part live in a global overflow buffer
+// (rarely touched: the stack only holds far siblings), so deep trees keep the occupancy of shallow ones.
+template <int STACK, bool OVF, bool PIX, bool STATS>
 __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];  // +1: pushes are unconditional
     uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
     const uint32_t n = *ta.count;
+    // overflow entries of this lane: index k at ovf[k * ovfStride]
+    uint32_t* ovf = OVF ? ta.overflow + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x : nullptr;
+    const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
 
     uint32_t cur = RT_CUR_IDLE;
     uint32_t id = 0, qidx = 0;
@@ -549,7 +555,13 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
                 const bool nearA = d1 <= d2;
                 const float dNear = nearA ? d1 : d2, dFar = nearA ? d2 : d1;
                 const uint32_t nW = __float_as_uint(nearA ? lo1.w : lo2.w), fW = __float_as_uint(nearA ? lo2.w : lo1.w);
-                stack[sp * RT_WAVE] = fW;          // ready-made word (pair index or leaf reference); kept only if it qualifies
+                // ready-made word (pair index or leaf reference); kept only if it qualifies
+                if (OVF) {
+                    stack[min(sp, (uint32_t)STACK) * RT_WAVE] = fW;
+                    if (sp >= (uint32_t)STACK && dFar < best) ovf[(sp - STACK) * ovfStride] = fW;
+                } else {
+                    stack[sp * RT_WAVE] = fW;
+                }
                 sp += (dFar < best) ? 1u : 0u;
                 cur = (dNear < best) ? nW : RT_CUR_NEED;
             }
@@ -559,7 +571,13 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
         {
             const bool need = cur == RT_CUR_NEED;
             const bool has = sp > 0;
-            const uint32_t top = stack[((has ? sp : 1u) - 1u) * RT_WAVE];
+            uint32_t top;
+            if (OVF) {
+                top = stack[min((has ? sp : 1u) - 1u, (uint32_t)STACK) * RT_WAVE];
+                if (need && sp > (uint32_t)STACK) top = ovf[(sp - 1u - STACK) * ovfStride];
+            } else {
+                top = stack[((has ? sp : 1u) - 1u) * RT_WAVE];
+            }
             const bool objLeft = obj < sc.objectCount;
             const bool ident = (nxFlags & 1u) && plain;  // identity transform: register moves only
             const uint32_t whenEmpty = objLeft ? (ident ? (atWorld ? nxW : RT_CUR_WORLD) : RT_CUR_SETUP) : RT_CUR_DONE;
