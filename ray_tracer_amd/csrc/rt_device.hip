@@ -62,7 +62,7 @@ struct rt_ctx {
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
     int refill = 8;         // k_trace_pw: idle lanes that trigger a refill
     int chunk = 256;        // k_trace_pw: most queue entries reserved per atomic
-    int ldsStackCap = 24;   // k_trace_pw: LDS stack entries per lane (16 or 24); deeper BVHs use the overflow buffer
+    int ldsStackCap = 24;   // k_trace_pw: LDS stack entries per lane (8, 16 or 24); deeper BVHs use the overflow buffer
     int fastLanes = 24;     // k_trace_pw: lanes at interior nodes that skip the full vote
     int wSetup = 32, wLeaf = 8; // k_trace_pw: vote weights in eighths (interior = 8)
     int blocksPerCU = 0;    // k_trace_pw: 0 = occupancy query
@@ -214,10 +214,11 @@ int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     } else {  // persistent waves; at most 24 entries in LDS, deeper ones in the overflow buffer
         const uint32_t cap = (uint32_t)c->ldsStackCap;
         if (d <= 8) rc = launch_pw_t<8, false>(c, maxRays, ta);
+        else if (cap < 16) rc = launch_pw_t<8, true>(c, maxRays, ta);
         else if (d <= 16) rc = launch_pw_t<16, false>(c, maxRays, ta);
-        else if (d <= 24 && cap >= 24) rc = launch_pw_t<24, false>(c, maxRays, ta);
-        else if (cap >= 24) rc = launch_pw_t<24, true>(c, maxRays, ta);
-        else rc = launch_pw_t<16, true>(c, maxRays, ta);
+        else if (cap < 24) rc = launch_pw_t<16, true>(c, maxRays, ta);
+        else if (d <= 24) rc = launch_pw_t<24, false>(c, maxRays, ta);
+        else rc = launch_pw_t<24, true>(c, maxRays, ta);
     }
     if (rc) return rc;
     RT_HIP(c, hipGetLastError());
@@ -709,7 +710,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     std::string k(key);
     if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
     else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; }
-    else if (k == "lds_stack") { if (value != 16 && value != 24) return c->fail("lds_stack: 16 or 24"); c->ldsStackCap = value; }
+    else if (k == "lds_stack") { if (value != 8 && value != 16 && value != 24) return c->fail("lds_stack: 8, 16 or 24"); c->ldsStackCap = value; }
     else if (k == "fast_lanes") { if (value < 1 || value > 65) return c->fail("fast_lanes: 1..65"); c->fastLanes = value; }
     else if (k == "chunk") { if (value < 1 || value > 4096) return c->fail("chunk: 1..4096"); c->chunk = value; }
     else if (k == "w_setup") { if (value < 1 || value > 512) return c->fail("w_setup: 1..512"); c->wSetup = value; }

@@ -236,3 +236,47 @@ def test_gpu_against_committed_golden_fixtures(renderer):
         renderer.upload_scene(sc)
         h = engine.hits_to_numpy(renderer.trace_rays(z["origins"], z["dirs"]))
         assert_hits_equal(h, {k: z[k] for k in h})
+
+
+def test_both_traversal_kernels_and_knobs_agree(renderer):
+    """k_trace (one ray per lane) and k_trace_pw (persistent waves) under several knob settings:
+    same pixels, same counters (the knobs are performance-only)."""
+    s = model_scene("bunny.obj", material=5, spheres=True)
+    W, H = 100, 50   # width not a multiple of 8: row-major slot order; 50 rows: 48 tiled + 2
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2)
+    ref, rc = pyoracle.render(s, pc, W, H)
+    renderer.upload_scene(s)
+    try:
+        for knobs in ({"trace_variant": 0}, {"trace_variant": 1}, {"trace_variant": 1, "refill": 1, "fast_lanes": 65},
+                      {"trace_variant": 1, "refill": 64, "chunk": 16, "w_setup": 1, "w_leaf": 64},
+                      {"trace_variant": 1, "lds_stack": 8, "tile_slots": 0, "blocks_per_cu": 1}):
+            for k, v in knobs.items():
+                renderer.set_tuning(k, v)
+            renderer.reset_counters()
+            img = renderer.render(pc, W, H)
+            _check(img, renderer.counters(), ref, rc)
+    finally:
+        for k, v in {"trace_variant": 1, "refill": 8, "fast_lanes": 24, "chunk": 256, "w_setup": 32, "w_leaf": 8,
+                     "lds_stack": 24, "tile_slots": 1, "blocks_per_cu": 0}.items():
+            renderer.set_tuning(k, v)
+    with pytest.raises(engine.RtError):
+        renderer.set_tuning("no_such_knob", 1)
+
+
+def test_overflow_stack_beyond_the_lds_part(renderer):
+    """With the LDS part of the traversal stack cut to 8 entries, the klein bottle's BVH (depth ~20)
+    and the bunny's keep spilling into the global overflow buffer: pixels and counters must not move."""
+    for name, kw in (("klein_bottle.obj", dict(material=4, scale=0.5, position=(0.0, -0.2, 0.0))), ("bunny.obj", dict(material=0))):
+        s = model_scene(name, **kw)
+        assert s.last_bvh_stats()["maxDepth"] > 8
+        W, H = 96, 64
+        pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2)
+        ref, rc = pyoracle.render(s, pc, W, H)
+        renderer.upload_scene(s)
+        try:
+            for cap in (8, 16, 24):
+                renderer.set_tuning("lds_stack", cap)
+                renderer.reset_counters()
+                _check(renderer.render(pc, W, H), renderer.counters(), ref, rc)
+        finally:
+            renderer.set_tuning("lds_stack", 24)
