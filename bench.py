@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket traversal launches with HIP events")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, default); gloo only to rehearse N ranks on ONE GPU (strips gathered through host memory)")
+    ap.add_argument("--tune", default="", help="comma-separated rt_set_tuning knobs, e.g. blocks_per_cu=2,refill=8")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole frame alone and compares it with the gathered one")
     args = ap.parse_args()
 
@@ -78,6 +79,9 @@ def main():
     r = engine.Renderer(local)
     if r.selftest() != 0x0F:
         raise SystemExit("device deterministic-math self-test failed")
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        r.set_tuning(k, int(v))
     r.upload_scene(scene)
     rows = tiling.rows_of_rank(H, rank, world)
     strip = torch.zeros((len(rows), W, 4), dtype=torch.float32, device=f"cuda:{local}")
