@@ -60,6 +60,7 @@ struct rt_ctx {
 
     // tuning (rt_set_tuning)
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
+    int pipeline = 0;       // 0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline (k_render_fused)
     int refill = 8;         // k_trace_pw: idle lanes that trigger a refill
     int chunk = 256;        // k_trace_pw: most queue entries reserved per atomic
     int ldsStackCap = 24;   // k_trace_pw: LDS stack entries per lane (8, 16 or 24); deeper BVHs use the overflow buffer
@@ -179,6 +180,55 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
     else if (pix) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
     else hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    return 0;
+}
+
+template <int STACK, bool OVF>
+int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
+    int perCU = c->blocksPerCU;
+    if (perCU <= 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_render_fused<STACK, OVF, false>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
+    }
+    const uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
+    const uint32_t nBatches = (fp.nPixels + RT_WAVE - 1) / RT_WAVE;
+    const uint32_t blocks = std::max(1u, std::min((nBatches + (RT_BLOCK / RT_WAVE) - 1) / (RT_BLOCK / RT_WAVE), resident));
+    uint32_t* overflow = nullptr;
+    if (OVF) {
+        int rc = dev_alloc(c, c->overflowBuf, (size_t)(c->maxLeafDepth - STACK) * resident * RT_BLOCK * 4);
+        if (rc) return rc;
+        overflow = (uint32_t*)c->overflowBuf.p;
+    }
+    RT_HIP(c, hipMemsetAsync(c->q.counts + 5, 0, 4, c->stream));
+    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes};
+    if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, fp, fa);
+    else hipLaunchKernelGGL((k_render_fused<STACK, OVF, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, fp, fa);
+    RT_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int launch_fused(rt_ctx* c, const FrameParams& fp, float4* fb) {
+    EventPair* ev = nullptr;
+    if (c->profiling) {
+        if (c->evUsed == c->evPool.size()) {
+            EventPair p;
+            RT_HIP(c, hipEventCreate(&p.a));
+            RT_HIP(c, hipEventCreate(&p.b));
+            c->evPool.push_back(p);
+        }
+        ev = &c->evPool[c->evUsed++];
+        RT_HIP(c, hipEventRecord(ev->a, c->stream));
+    }
+    const uint32_t d = c->maxLeafDepth, cap = (uint32_t)c->ldsStackCap;
+    int rc;
+    if (d <= 8) rc = launch_fused_t<8, false>(c, fp, fb);
+    else if (cap < 16) rc = launch_fused_t<8, true>(c, fp, fb);
+    else if (d <= 16) rc = launch_fused_t<16, false>(c, fp, fb);
+    else if (cap < 24) rc = launch_fused_t<16, true>(c, fp, fb);
+    else if (d <= 24) rc = launch_fused_t<24, false>(c, fp, fb);
+    else rc = launch_fused_t<24, true>(c, fp, fb);
+    if (rc) return rc;
+    if (ev) RT_HIP(c, hipEventRecord(ev->b, c->stream));
+    c->traceLaunchesTotal++;
     return 0;
 }
 
@@ -557,6 +607,11 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     DevCounters* dc = (DevCounters*)c->counterBuf.p;
     uint32_t* counts = c->q.counts;
 
+    if (c->pipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch
+        rc = launch_fused(c, fp, fb);
+        c->sc = saved;
+        return rc;
+    }
     hipLaunchKernelGGL(k_raygen, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, c->q, fp);
     RT_HIP(c, hipGetLastError());
 
@@ -708,7 +763,8 @@ int rt_get_trace_time_ms(rt_ctx* c, double* ms, uint64_t* launches) {
 int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     if (!c || !key) return -1;
     std::string k(key);
-    if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
+    if (k == "pipeline") { if (value < 0 || value > 1) return c->fail("pipeline: 0 or 1"); c->pipeline = value; }
+    else if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
     else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; }
     else if (k == "lds_stack") { if (value != 8 && value != 16 && value != 24) return c->fail("lds_stack: 8, 16 or 24"); c->ldsStackCap = value; }
     else if (k == "fast_lanes") { if (value < 1 || value > 65) return c->fail("fast_lanes: 1..65"); c->fastLanes = value; }

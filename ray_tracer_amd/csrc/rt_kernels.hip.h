@@ -386,24 +386,26 @@ struct TracePwArgs {
     uint32_t* overflow;       // OVF only: stack entries beyond STACK, (maxDepth - STACK) x resident lanes
 };
 
-// Instruction issue, scalar and vector alike, is what bounds this kernel (measured: ~110 VALU +
+// Counters a wave accumulates while it traces (reduced once per kernel).
+struct WaveTotals {
+    uint32_t totBox = 0, totTri = 0, totRays = 0, totHits = 0;
+    uint32_t dbgRounds[4] = {0, 0, 0, 0}, dbgLanes[4] = {0, 0, 0, 0};  // refill, setup, interior, leaf (STATS)
+};
+
+// OVF: the BVH is deeper than STACK; entries beyond the LDS part live in a global overflow buffer
+// (rarely touched: the stack only holds far siblings), so deep trees keep the occupancy of shallow ones.
+// LOCAL: the rays come from the wave's own list in LDS (k_render_fused) instead of the global queue.
+//
+// Instruction issue, scalar and vector alike, is what bounds this loop (measured: ~110 VALU +
 // ~100 SALU + 16 branches per round kept both issue ports ~70 % busy while the L1 and L2 idled;
 // serving half of the node fetches from LDS changed nothing). So the hot round is written with as
 // little control flow as possible: one ballot decides "enough lanes are at an interior node" and
 // goes straight to the interior step; pushes and pops are unconditional LDS accesses with
 // predicated pointer updates; the full vote, the refill and the leaf / setup steps live on a slow
 // path that is only entered when fewer than `fastLanes` lanes are at interior nodes.
-// OVF: the BVH is deeper than STACK; entries beyond the LDS part live in a global overflow buffer
-// (rarely touched: the stack only holds far siblings), so deep trees keep the occupancy of shallow ones.
-template <int STACK, bool OVF, bool PIX, bool STATS>
-__global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
-    __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];  // +1: pushes are unconditional
-    uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
-    const uint32_t n = *ta.count;
-    // overflow entries of this lane: index k at ovf[k * ovfStride]
-    uint32_t* ovf = OVF ? ta.overflow + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x : nullptr;
-    const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
-
+template <int STACK, bool OVF, bool PIX, bool STATS, bool LOCAL>
+__device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& ps, const TracePwArgs& ta, uint32_t* stack, uint32_t* ovf,
+                                           size_t ovfStride, const uint32_t* localList, uint32_t n, WaveTotals& wt) {
     uint32_t cur = RT_CUR_IDLE;
     uint32_t id = 0, qidx = 0;
     rt_vec3 tro = rt_v3(0, 0, 0), trd = tro, inv = tro;  // ray in the current object's space, 1/dir (written by the setup step only)
@@ -414,11 +416,10 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
     uint32_t obj = 0, sp = 0;
     uint32_t nxW = 0, nxFlags = 0;   // objMeta of object `obj`, fetched ahead of its use
     uint32_t rayBox = 0, rayTri = 0;  // PIX: this ray's counters
-    uint32_t totBox = 0, totTri = 0, totRays = 0, totHits = 0;
-    bool exhausted = false;               // wave-uniform: the queue has no entries left to reserve
-    uint32_t resBase = 0, resCount = 0;   // wave-uniform: reserved queue entries not yet dealt out
-    uint32_t nextChunk = min(ta.chunk, max(16u, n / (2u * gridDim.x * (RT_BLOCK / RT_WAVE))));
-    uint32_t dbgRounds[4] = {0, 0, 0, 0}, dbgLanes[4] = {0, 0, 0, 0};  // refill, setup, interior, leaf
+    // wave-uniform refill state. LOCAL: the wave's own ray list is the whole 'queue', already reserved.
+    bool exhausted = LOCAL;               // the queue has no entries left to reserve
+    uint32_t resBase = 0, resCount = LOCAL ? n : 0u;  // reserved queue entries not yet dealt out
+    uint32_t nextChunk = LOCAL ? 0u : min(ta.chunk, max(16u, n / (2u * gridDim.x * (RT_BLOCK / RT_WAVE))));
 
     auto fetch_next_meta = [&]() {
         if (obj < sc.objectCount) {
@@ -451,12 +452,12 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
                     nextChunk = min(ta.chunk, max(16u, left / (2u * gridDim.x * (RT_BLOCK / RT_WAVE))));
                 }
                 const uint32_t take = min(nIdle, resCount);
-                if (STATS) { dbgRounds[0]++; dbgLanes[0] += take; }
+                if (STATS) { wt.dbgRounds[0]++; wt.dbgLanes[0] += take; }
                 if (cur == RT_CUR_IDLE) {
                     const uint32_t rk = lanes_below(mIdle);
                     if (rk < take) {
                         qidx = resBase + rk;
-                        id = ta.queue ? ta.queue[qidx] : (qidx << 2);
+                        id = LOCAL ? localList[qidx] : (ta.queue ? ta.queue[qidx] : (qidx << 2));
                         cur = RT_CUR_INIT;
                     }
                 }
@@ -472,8 +473,8 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
             const bool runL = !runI && nL && scL >= scS;
             const bool runS = !runI && !runL && nS;
             if (STATS) {
-                if (runL) { dbgRounds[3]++; dbgLanes[3] += nL; }
-                else if (runS) { dbgRounds[1]++; dbgLanes[1] += nS; }
+                if (runL) { wt.dbgRounds[3]++; wt.dbgLanes[3] += nL; }
+                else if (runS) { wt.dbgRounds[1]++; wt.dbgLanes[1] += nS; }
             }
 
             if (runL) {
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
                         jEnd = j + 1;
                         cur = (cnt > 1u) ? (cur + 1u - (1u << RT_LEAF_CNT_SHIFT)) : RT_CUR_NEED;
                     }
-                    if (PIX) rayTri += jEnd - j; else totTri += jEnd - j;
+                    if (PIX) rayTri += jEnd - j; else wt.totTri += jEnd - j;
                     for (; j < jEnd; j++) {
                         const float4 a = sc.triPos[3 * (size_t)j], b = sc.triPos[3 * (size_t)j + 1], c = sc.triPos[3 * (size_t)j + 2];
                         const TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
                                 rt_f2u(wo.x) != 0x80000000u && rt_f2u(wo.y) != 0x80000000u && rt_f2u(wo.z) != 0x80000000u;
                         obj = 0; sp = 0;
                         if (PIX) { rayBox = 0; rayTri = 0; }
-                        totRays++;
+                        wt.totRays++;
                         fetch_next_meta();
                     }
                     const bool general = cur == RT_CUR_SETUP;
@@ -545,13 +546,13 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
 
         if (runI) {
             // ================= interior step: both children of the pair `cur` =================
-            if (STATS) { dbgRounds[2]++; dbgLanes[2] += nI; }
+            if (STATS) { wt.dbgRounds[2]++; wt.dbgLanes[2] += nI; }
             if ((int32_t)cur >= 0) {
                 const float4* pr = sc.nodes + 2 * (size_t)cur;
                 const float4 lo1 = pr[0], hi1 = pr[1], lo2 = pr[2], hi2 = pr[3];
                 const float d1 = box_intersect(lo1, hi1, tro, inv);
                 const float d2 = box_intersect(lo2, hi2, tro, inv);
-                if (PIX) rayBox += 2; else totBox += 2;
+                if (PIX) rayBox += 2; else wt.totBox += 2;
                 const bool nearA = d1 <= d2;
                 const float dNear = nearA ? d1 : d2, dFar = nearA ? d2 : d1;
                 const uint32_t nW = __float_as_uint(nearA ? lo1.w : lo2.w), fW = __float_as_uint(nearA ? lo2.w : lo1.w);
@@ -594,25 +595,37 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
                 if (PIX && kind == RAY_MAIN) { ps.statBox[slot] += rayBox; ps.statTri[slot] += rayTri; }
                 if (PIX) {
                     if (ta.perRayBox) { ta.perRayBox[qidx] = rayBox; ta.perRayTri[qidx] = rayTri; }
-                    totBox += rayBox; totTri += rayTri;
+                    wt.totBox += rayBox; wt.totTri += rayTri;
                 }
-                totHits += (bestObj != RT_HIT_NONE) ? 1u : 0u;
+                wt.totHits += (bestObj != RT_HIT_NONE) ? 1u : 0u;
                 cur = RT_CUR_IDLE;
             }
         }
     }
 
+}
+
+template <int STACK, bool OVF, bool PIX, bool STATS>
+__global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
+    __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];  // +1: pushes are unconditional
+    uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
+    // overflow entries of this lane: index k at ovf[k * ovfStride]
+    uint32_t* ovf = OVF ? ta.overflow + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x : nullptr;
+    const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
+    WaveTotals wt;
+    trace_wave<STACK, OVF, PIX, STATS, false>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt);
+
     if (STATS && lane_id() == 0) {
         for (int k = 0; k < 4; k++) {
-            atomicAdd(&ta.phaseStats[k], (unsigned long long)dbgRounds[k]);
-            atomicAdd(&ta.phaseStats[4 + k], (unsigned long long)dbgLanes[k]);
+            atomicAdd(&ta.phaseStats[k], (unsigned long long)wt.dbgRounds[k]);
+            atomicAdd(&ta.phaseStats[4 + k], (unsigned long long)wt.dbgLanes[k]);
         }
     }
-    unsigned long long wb = wave_sum_u64(totBox), wt = wave_sum_u64(totTri);
-    uint32_t wr = wave_sum_u32(totRays), wh = wave_sum_u32(totHits);
+    unsigned long long wb = wave_sum_u64(wt.totBox), wtri = wave_sum_u64(wt.totTri);
+    uint32_t wr = wave_sum_u32(wt.totRays), wh = wave_sum_u32(wt.totHits);
     if (lane_id() == 0 && wr) {
         atomicAdd(&ta.counters->boxTests, wb);
-        atomicAdd(&ta.counters->triTests, wt);
+        atomicAdd(&ta.counters->triTests, wtri);
         atomicAdd(&ta.counters->raysTraced, (unsigned long long)wr);
         atomicAdd(&ta.counters->raysHit, (unsigned long long)wh);
     }
@@ -725,9 +738,8 @@ __device__ __forceinline__ void slot_to_pixel(const FrameParams& fp, uint32_t sl
 }
 
 // ---------------------------------------------------------------- k_raygen
-__global__ __launch_bounds__(RT_BLOCK) void k_raygen(DevScene sc, PathState ps, Queues q, FrameParams fp) {
-    uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (slot >= fp.nPixels) return;
+// raytrace.comp:547-564 for the pixel of `slot`: camera ray, RNG seed, path reset, sphere seed
+__device__ __forceinline__ void init_path(const DevScene& sc, const PathState& ps, const FrameParams& fp, uint32_t slot) {
     uint32_t gx, gy;
     uint32_t krow;
     slot_to_pixel(fp, slot, gx, gy, krow);
@@ -741,6 +753,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(DevScene sc, PathState ps, 
     ps.accum[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     ps.statBox[slot] = 0;
     ps.statTri[slot] = 0;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(DevScene sc, PathState ps, Queues q, FrameParams fp) {
+    uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (slot >= fp.nPixels) return;
+    init_path(sc, ps, fp, slot);
     q.active[0][slot] = slot;
     q.rays[0][slot] = slot << 2;
 }
@@ -756,6 +774,189 @@ struct ShadeArgs {
     DevCounters* counters;
 };
 
+// One path, one segment: trace()'s loop body (raytrace.comp:495-534) with diffuseBRDF split around the
+// probe rays, plus main()'s sample loop (:571-573). Reads the hit records of the path's rays, writes
+// its next rays. Outputs: alive (a main ray was emitted), wantAux (and two probe rays), refRays (the
+// shader's calculateIntersections calls for this segment), nPaths (1 if a sample finished).
+__device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& ps, const FrameParams& fp, uint32_t slot, bool& alive,
+                                           bool& wantAux, uint32_t& refRays, uint32_t& nPaths) {
+    rt_vec3 auxOrigin = rt_v3(0, 0, 0), auxL = auxOrigin, auxC = auxOrigin;  // probe rays of this bounce (diffuse only)
+    const float4 sO = ps.rayO[slot], sD = ps.rayD[slot], sA = ps.att[slot], sT = ps.total[slot], sDi = ps.direct[slot];
+    const float4 hM = ps.hit[RAY_MAIN][slot];
+    rt_vec3 ro = f4xyz(sO), rd = f4xyz(sD);
+    rt_vec3 att = f4xyz(sA), total = f4xyz(sT), direct = f4xyz(sDi);
+    float misW = sO.w;
+    uint32_t state = __float_as_uint(sD.w);
+    uint32_t jraw = __float_as_uint(sA.w);
+    uint32_t samplesDone = __float_as_uint(sT.w);
+    uint32_t j = jraw & 0x7fffffffu;
+    const bool pending = (jraw >> 31) != 0u;
+
+    const uint32_t obj = __float_as_uint(hM.y);
+    const uint32_t hitTriIdx = __float_as_uint(hM.z);
+    refRays = 1;  // this segment's calculateIntersections (raytrace.comp:496)
+
+    bool done = false;       // this sample's trace() returned
+    bool zeroed = false;     // ... through the NaN/negative early-out (:505)
+
+    if (obj != RT_HIT_NONE) {
+        if (pending) {
+            // finish diffuseBRDF of the previous bounce (:443-460); its three
+            // scene queries were the NEE ray (once for :443 and :447) and the
+            // cosine probe (:453)
+            const float4 hL = ps.hit[RAY_NEE][slot], hC = ps.hit[RAY_PROBE][slot];
+            const float4 aO = ps.auxO[slot], aL = ps.auxDL[slot], aC = ps.auxDC[slot];
+            float tL = hL.x, tC = hC.x;
+            uint32_t oL = __float_as_uint(hL.y), oC = __float_as_uint(hC.y);
+            rt_vec3 dL = f4xyz(aL), dC = f4xyz(aC);
+            uint32_t lm = (oL == RT_HIT_NONE) ? 0u : hit_material(sc, oL);
+            float4 lmE = sc.mats[3 * lm + 1];
+            float realLightPDF = light_sample_pdf(sc, tL, oL, dL);
+            float cosinePDF = aL.w;
+            float misWeight1 = realLightPDF * realLightPDF / (realLightPDF * realLightPDF + cosinePDF * cosinePDF);
+            if (rt_isnan(misWeight1)) misWeight1 = 0.f;
+            float lightPDF = light_sample_pdf(sc, tC, oC, dC);
+            float realCosinePDF = aC.w;
+            float misWeight2 = realCosinePDF * realCosinePDF / (lightPDF * lightPDF + realCosinePDF * realCosinePDF);
+            if (rt_isnan(misWeight2)) misWeight2 = 0.f;
+            rt_vec3 albedo = f4xyz(ps.pendAlbedo[slot]);
+            rt_vec3 dl = rt_scale(rt_v3(lmE.x, lmE.y, lmE.z), lmE.w);
+            float k = (realLightPDF == 0.f) ? 0.f : misWeight1 / realLightPDF;
+            rt_vec3 f = rt_scale(rt_scale(rt_scale(albedo, RT_INV_PI), aO.w), k);
+            direct = rt_mul(dl, f);
+            misW = misWeight2;
+        }
+
+        FullHit hit = reconstruct_hit(sc, ro, rd, obj, hitTriIdx);
+        float4 mA = sc.mats[3 * hit.materialIndex], mE = sc.mats[3 * hit.materialIndex + 1], mI = sc.mats[3 * hit.materialIndex + 2];
+
+        // 0-1 NEE (:501-505)
+        rt_vec3 emission = rt_scale(rt_v3(mE.x, mE.y, mE.z), mE.w);
+        emission = rt_v3(emission.x / misW, emission.y / misW, emission.z / misW);
+        rt_vec3 finalLight = direct.x == -1.f ? emission : direct;
+        total = rt_add(total, rt_mul(finalLight, att));
+        if (j == 0) total = rt_add(total, emission);
+        if (rt_isnan(total.x) || rt_isnan(total.y) || rt_isnan(total.z) || total.x < 0.f || total.y < 0.f || total.z < 0.f) {
+            done = true;
+            zeroed = true;
+        } else {
+            rt_vec3 sampledDir, radiance;
+            float originSign = 1.f;
+            bool diffuse = false;
+            if (mA.w != 0.f) {  // reflectance != 0: mirror (:466-469)
+                sampledDir = rt_reflect(rd, hit.normal);
+                radiance = rt_v3(1.f, 1.f, 1.f);
+                direct = rt_v3(-1.f, -1.f, -1.f);
+                misW = 1.f;
+            } else if (mI.x != -1.f) {  // dielectric (:471-481)
+                float ior = !hit.frontFace ? mI.x : 1.f / mI.x;
+                float cosine = rt_dot(rt_neg(rd), hit.normal);
+                float sine = rt_sqrt(1.f - cosine * cosine);
+                bool solution = (ior * sine) > 1.f;
+                if (!solution) solution = schlick(cosine, ior) > rt_random(&state);
+                sampledDir = solution ? rt_reflect(rd, hit.normal) : rt_refract(rd, hit.normal, ior);
+                originSign = solution ? 1.f : rt_sign(rt_dot(hit.normal, rd));
+                radiance = rt_v3(1.f, 1.f, 1.f);
+                direct = rt_v3(-1.f, -1.f, -1.f);
+                misW = 1.f;
+            } else {  // diffuse + NEE/MIS (:430-464), first half
+                diffuse = true;
+                refRays += 3;
+                rt_vec3 albedo = rt_v3(mA.x, mA.y, mA.z);
+                rt_vec3 origin = rt_add(hit.hitPoint, rt_scale(hit.normal, 0.01f));
+                // lightSampleDir (:368-387)
+                float lx = rt_random(&state);
+                float lz = rt_random(&state);
+                rt_vec3 lp = rt_v3(rt_mix(-0.33333f, 0.33333f, lx), -1.5f, rt_mix(-0.33333f, 0.33333f, lz));
+                rt_vec3 lightSample = rt_normalize(rt_sub(lp, origin));
+                // cosineHemisphereDir (:405-424)
+                float r1 = rt_random(&state);
+                float r2 = rt_random(&state);
+                float phi = (2.f * RT_PI) * r1;
+                float sqrtR2 = rt_sqrt(r2);
+                float sn, cs;
+                rt_sincos(phi, &sn, &cs);
+                float x = cs * sqrtR2, y = sn * sqrtR2, z = rt_sqrt(1.f - r2);
+                rt_vec3 axis = rt_abs(rt_dot(hit.normal, rt_v3(1.f, 0.f, 0.f))) < 1.f ? rt_v3(1.f, 0.f, 0.f) : rt_v3(0.f, 0.f, 1.f);
+                rt_vec3 tt = rt_normalize(rt_cross(hit.normal, axis));
+                rt_vec3 bb = rt_cross(hit.normal, tt);
+                rt_vec3 cosineSample = rt_add(rt_add(rt_scale(tt, x), rt_scale(bb, y)), rt_scale(hit.normal, z));
+
+                float realCosinePDF = rt_max(0.f, rt_dot(cosineSample, hit.normal) * RT_INV_PI);
+                float nDotC = rt_dot(hit.normal, cosineSample);
+                radiance = rt_scale(rt_scale(albedo, RT_INV_PI), nDotC);
+                radiance = rt_v3(radiance.x / realCosinePDF, radiance.y / realCosinePDF, radiance.z / realCosinePDF);
+                sampledDir = cosineSample;
+
+                auxOrigin = origin; auxL = lightSample; auxC = cosineSample;
+                ps.auxO[slot] = mk4(origin, rt_max(0.f, rt_dot(hit.normal, lightSample)));
+                ps.auxDL[slot] = mk4(lightSample, rt_max(0.f, rt_dot(lightSample, hit.normal) * RT_INV_PI));
+                ps.auxDC[slot] = mk4(cosineSample, realCosinePDF);
+                ps.pendAlbedo[slot] = mk4(albedo, 0.f);
+            }
+            att = rt_mul(att, radiance);
+
+            // russian roulette (:520-524)
+            float rrProb = rt_max(rt_max(att.x, att.y), att.z);
+            rrProb = rt_min(rrProb, 0.95f);
+            rrProb = j <= 5 ? 1.f : rrProb;
+            if (rt_random(&state) > rrProb) {
+                done = true;
+            } else {
+                float invP = 1.f / rrProb;
+                att = rt_scale(att, invP);
+                ro = rt_add(hit.hitPoint, rt_scale(rt_scale(hit.normal, originSign), 0.00001f));
+                rd = sampledDir;
+                j++;
+                if (j > fp.bounceLimit) done = true;  // the for loop ends (:495)
+                else wantAux = diffuse;
+            }
+        }
+    } else {
+        // miss (:532-533)
+        total = rt_add(total, rt_mul(att, environment_light(fp.env, rd)));
+        done = true;
+    }
+
+    if (done) {
+        nPaths = 1;
+        float4 acc = ps.accum[slot];
+        if (zeroed) total = rt_v3(0.f, 0.f, 0.f);
+        const rt_vec3 sum = rt_add(f4xyz(acc), total);
+        ps.accum[slot] = mk4(sum, 0.f);
+        samplesDone++;
+        if (samplesDone < fp.samples) {
+            // next sample of this pixel: same primary ray, RNG state runs on (:571-573)
+            uint32_t gx, gy, krow;
+            slot_to_pixel(fp, slot, gx, gy, krow);
+            ro = rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]);
+            rd = primary_dir(fp, gx, gy);
+            att = rt_v3(1.f, 1.f, 1.f);
+            total = rt_v3(0.f, 0.f, 0.f);
+            direct = rt_v3(0.f, 0.f, 0.f);
+            misW = 1.f;
+            j = 0;
+            alive = true;
+            wantAux = false;
+        }
+    } else {
+        alive = true;
+    }
+
+    if (alive) {
+        ps.hit[RAY_MAIN][slot] = sphere_seed(sc, ro, rd);
+        if (wantAux) {
+            ps.hit[RAY_NEE][slot] = sphere_seed(sc, auxOrigin, auxL);
+            ps.hit[RAY_PROBE][slot] = sphere_seed(sc, auxOrigin, auxC);
+        }
+        ps.rayO[slot] = mk4(ro, misW);
+        ps.rayD[slot] = mk4u(rd, state);
+        ps.att[slot] = mk4u(att, j | (wantAux ? 0x80000000u : 0u));
+        ps.total[slot] = mk4u(total, samplesDone);
+        ps.direct[slot] = mk4(direct, 0.f);
+    }
+}
+
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, ShadeArgs sa, FrameParams fp) {
     __shared__ uint32_t s_cnt[RT_BLOCK / RT_WAVE][5];  // per wave: alive, aux, refRays, paths, segments
     __shared__ uint32_t s_base[2];
@@ -764,188 +965,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
     const uint32_t gid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const bool live = gid < n;
 
-    rt_vec3 auxOrigin = rt_v3(0, 0, 0), auxL = auxOrigin, auxC = auxOrigin;  // probe rays of this bounce (diffuse only)
     bool alive = false;    // path (or its successor sample) has a main ray for the next round
     bool wantAux = false;  // and two probe rays
     uint32_t slot = 0;
     uint32_t refRays = 0, nPaths = 0;
-
     if (live) {
         slot = sa.inActive[gid];
-        const float4 sO = ps.rayO[slot], sD = ps.rayD[slot], sA = ps.att[slot], sT = ps.total[slot], sDi = ps.direct[slot];
-        const float4 hM = ps.hit[RAY_MAIN][slot];
-        rt_vec3 ro = f4xyz(sO), rd = f4xyz(sD);
-        rt_vec3 att = f4xyz(sA), total = f4xyz(sT), direct = f4xyz(sDi);
-        float misW = sO.w;
-        uint32_t state = __float_as_uint(sD.w);
-        uint32_t jraw = __float_as_uint(sA.w);
-        uint32_t samplesDone = __float_as_uint(sT.w);
-        uint32_t j = jraw & 0x7fffffffu;
-        const bool pending = (jraw >> 31) != 0u;
-
-        const uint32_t obj = __float_as_uint(hM.y);
-        const uint32_t hitTriIdx = __float_as_uint(hM.z);
-        refRays = 1;  // this segment's calculateIntersections (raytrace.comp:496)
-
-        bool done = false;       // this sample's trace() returned
-        bool zeroed = false;     // ... through the NaN/negative early-out (:505)
-
-        if (obj != RT_HIT_NONE) {
-            if (pending) {
-                // finish diffuseBRDF of the previous bounce (:443-460); its three
-                // scene queries were the NEE ray (once for :443 and :447) and the
-                // cosine probe (:453)
-                const float4 hL = ps.hit[RAY_NEE][slot], hC = ps.hit[RAY_PROBE][slot];
-                const float4 aO = ps.auxO[slot], aL = ps.auxDL[slot], aC = ps.auxDC[slot];
-                float tL = hL.x, tC = hC.x;
-                uint32_t oL = __float_as_uint(hL.y), oC = __float_as_uint(hC.y);
-                rt_vec3 dL = f4xyz(aL), dC = f4xyz(aC);
-                uint32_t lm = (oL == RT_HIT_NONE) ? 0u : hit_material(sc, oL);
-                float4 lmE = sc.mats[3 * lm + 1];
-                float realLightPDF = light_sample_pdf(sc, tL, oL, dL);
-                float cosinePDF = aL.w;
-                float misWeight1 = realLightPDF * realLightPDF / (realLightPDF * realLightPDF + cosinePDF * cosinePDF);
-                if (rt_isnan(misWeight1)) misWeight1 = 0.f;
-                float lightPDF = light_sample_pdf(sc, tC, oC, dC);
-                float realCosinePDF = aC.w;
-                float misWeight2 = realCosinePDF * realCosinePDF / (lightPDF * lightPDF + realCosinePDF * realCosinePDF);
-                if (rt_isnan(misWeight2)) misWeight2 = 0.f;
-                rt_vec3 albedo = f4xyz(ps.pendAlbedo[slot]);
-                rt_vec3 dl = rt_scale(rt_v3(lmE.x, lmE.y, lmE.z), lmE.w);
-                float k = (realLightPDF == 0.f) ? 0.f : misWeight1 / realLightPDF;
-                rt_vec3 f = rt_scale(rt_scale(rt_scale(albedo, RT_INV_PI), aO.w), k);
-                direct = rt_mul(dl, f);
-                misW = misWeight2;
-            }
-
-            FullHit hit = reconstruct_hit(sc, ro, rd, obj, hitTriIdx);
-            float4 mA = sc.mats[3 * hit.materialIndex], mE = sc.mats[3 * hit.materialIndex + 1], mI = sc.mats[3 * hit.materialIndex + 2];
-
-            // 0-1 NEE (:501-505)
-            rt_vec3 emission = rt_scale(rt_v3(mE.x, mE.y, mE.z), mE.w);
-            emission = rt_v3(emission.x / misW, emission.y / misW, emission.z / misW);
-            rt_vec3 finalLight = direct.x == -1.f ? emission : direct;
-            total = rt_add(total, rt_mul(finalLight, att));
-            if (j == 0) total = rt_add(total, emission);
-            if (rt_isnan(total.x) || rt_isnan(total.y) || rt_isnan(total.z) || total.x < 0.f || total.y < 0.f || total.z < 0.f) {
-                done = true;
-                zeroed = true;
-            } else {
-                rt_vec3 sampledDir, radiance;
-                float originSign = 1.f;
-                bool diffuse = false;
-                if (mA.w != 0.f) {  // reflectance != 0: mirror (:466-469)
-                    sampledDir = rt_reflect(rd, hit.normal);
-                    radiance = rt_v3(1.f, 1.f, 1.f);
-                    direct = rt_v3(-1.f, -1.f, -1.f);
-                    misW = 1.f;
-                } else if (mI.x != -1.f) {  // dielectric (:471-481)
-                    float ior = !hit.frontFace ? mI.x : 1.f / mI.x;
-                    float cosine = rt_dot(rt_neg(rd), hit.normal);
-                    float sine = rt_sqrt(1.f - cosine * cosine);
-                    bool solution = (ior * sine) > 1.f;
-                    if (!solution) solution = schlick(cosine, ior) > rt_random(&state);
-                    sampledDir = solution ? rt_reflect(rd, hit.normal) : rt_refract(rd, hit.normal, ior);
-                    originSign = solution ? 1.f : rt_sign(rt_dot(hit.normal, rd));
-                    radiance = rt_v3(1.f, 1.f, 1.f);
-                    direct = rt_v3(-1.f, -1.f, -1.f);
-                    misW = 1.f;
-                } else {  // diffuse + NEE/MIS (:430-464), first half
-                    diffuse = true;
-                    refRays += 3;
-                    rt_vec3 albedo = rt_v3(mA.x, mA.y, mA.z);
-                    rt_vec3 origin = rt_add(hit.hitPoint, rt_scale(hit.normal, 0.01f));
-                    // lightSampleDir (:368-387)
-                    float lx = rt_random(&state);
-                    float lz = rt_random(&state);
-                    rt_vec3 lp = rt_v3(rt_mix(-0.33333f, 0.33333f, lx), -1.5f, rt_mix(-0.33333f, 0.33333f, lz));
-                    rt_vec3 lightSample = rt_normalize(rt_sub(lp, origin));
-                    // cosineHemisphereDir (:405-424)
-                    float r1 = rt_random(&state);
-                    float r2 = rt_random(&state);
-                    float phi = (2.f * RT_PI) * r1;
-                    float sqrtR2 = rt_sqrt(r2);
-                    float sn, cs;
-                    rt_sincos(phi, &sn, &cs);
-                    float x = cs * sqrtR2, y = sn * sqrtR2, z = rt_sqrt(1.f - r2);
-                    rt_vec3 axis = rt_abs(rt_dot(hit.normal, rt_v3(1.f, 0.f, 0.f))) < 1.f ? rt_v3(1.f, 0.f, 0.f) : rt_v3(0.f, 0.f, 1.f);
-                    rt_vec3 tt = rt_normalize(rt_cross(hit.normal, axis));
-                    rt_vec3 bb = rt_cross(hit.normal, tt);
-                    rt_vec3 cosineSample = rt_add(rt_add(rt_scale(tt, x), rt_scale(bb, y)), rt_scale(hit.normal, z));
-
-                    float realCosinePDF = rt_max(0.f, rt_dot(cosineSample, hit.normal) * RT_INV_PI);
-                    float nDotC = rt_dot(hit.normal, cosineSample);
-                    radiance = rt_scale(rt_scale(albedo, RT_INV_PI), nDotC);
-                    radiance = rt_v3(radiance.x / realCosinePDF, radiance.y / realCosinePDF, radiance.z / realCosinePDF);
-                    sampledDir = cosineSample;
-
-                    auxOrigin = origin; auxL = lightSample; auxC = cosineSample;
-                    ps.auxO[slot] = mk4(origin, rt_max(0.f, rt_dot(hit.normal, lightSample)));
-                    ps.auxDL[slot] = mk4(lightSample, rt_max(0.f, rt_dot(lightSample, hit.normal) * RT_INV_PI));
-                    ps.auxDC[slot] = mk4(cosineSample, realCosinePDF);
-                    ps.pendAlbedo[slot] = mk4(albedo, 0.f);
-                }
-                att = rt_mul(att, radiance);
-
-                // russian roulette (:520-524)
-                float rrProb = rt_max(rt_max(att.x, att.y), att.z);
-                rrProb = rt_min(rrProb, 0.95f);
-                rrProb = j <= 5 ? 1.f : rrProb;
-                if (rt_random(&state) > rrProb) {
-                    done = true;
-                } else {
-                    float invP = 1.f / rrProb;
-                    att = rt_scale(att, invP);
-                    ro = rt_add(hit.hitPoint, rt_scale(rt_scale(hit.normal, originSign), 0.00001f));
-                    rd = sampledDir;
-                    j++;
-                    if (j > fp.bounceLimit) done = true;  // the for loop ends (:495)
-                    else wantAux = diffuse;
-                }
-            }
-        } else {
-            // miss (:532-533)
-            total = rt_add(total, rt_mul(att, environment_light(fp.env, rd)));
-            done = true;
-        }
-
-        if (done) {
-            nPaths = 1;
-            float4 acc = ps.accum[slot];
-            if (zeroed) total = rt_v3(0.f, 0.f, 0.f);
-            const rt_vec3 sum = rt_add(f4xyz(acc), total);
-            ps.accum[slot] = mk4(sum, 0.f);
-            samplesDone++;
-            if (samplesDone < fp.samples) {
-                // next sample of this pixel: same primary ray, RNG state runs on (:571-573)
-                uint32_t gx, gy, krow;
-                slot_to_pixel(fp, slot, gx, gy, krow);
-                ro = rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]);
-                rd = primary_dir(fp, gx, gy);
-                att = rt_v3(1.f, 1.f, 1.f);
-                total = rt_v3(0.f, 0.f, 0.f);
-                direct = rt_v3(0.f, 0.f, 0.f);
-                misW = 1.f;
-                j = 0;
-                alive = true;
-                wantAux = false;
-            }
-        } else {
-            alive = true;
-        }
-
-        if (alive) {
-            ps.hit[RAY_MAIN][slot] = sphere_seed(sc, ro, rd);
-            if (wantAux) {
-                ps.hit[RAY_NEE][slot] = sphere_seed(sc, auxOrigin, auxL);
-                ps.hit[RAY_PROBE][slot] = sphere_seed(sc, auxOrigin, auxC);
-            }
-            ps.rayO[slot] = mk4(ro, misW);
-            ps.rayD[slot] = mk4u(rd, state);
-            ps.att[slot] = mk4u(att, j | (wantAux ? 0x80000000u : 0u));
-            ps.total[slot] = mk4u(total, samplesDone);
-            ps.direct[slot] = mk4(direct, 0.f);
-        }
+        shade_path(sc, ps, fp, slot, alive, wantAux, refRays, nPaths);
     }
 
     // Queue compaction: ranks inside a wave from ballots, wave offsets through LDS, and ONE atomic
@@ -988,9 +1014,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
 // ---------------------------------------------------------------- k_resolve
 // raytrace.comp:574-593. `rgba` holds the previous frame when progressive
 // (kept in fp32 instead of the reference's 8-bit image).
-__global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathState ps, FrameParams fp, float4* rgba) {
-    uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (slot >= fp.nPixels) return;
+__device__ __forceinline__ void resolve_pixel(const PathState& ps, const FrameParams& fp, float4* rgba, uint32_t slot) {
     rt_vec3 out = f4xyz(ps.accum[slot]);
     float fs = (float)fp.samples;
     out = rt_v3(out.x / fs, out.y / fs, out.z / fs);
@@ -1013,6 +1037,99 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathState ps, FrameParams 
         fin = rt_v3(s0 / boxCap, 0.f, s1 / triCap);
     }
     rgba[px] = make_float4(fin.x, fin.y, fin.z, 1.f);
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathState ps, FrameParams fp, float4* rgba) {
+    uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (slot >= fp.nPixels) return;
+    resolve_pixel(ps, fp, rgba, slot);
+}
+
+// ---------------------------------------------------------------- k_render_fused (wave-private pipeline)
+// The same stages, run by each wave on its own 8x8 pixel block: init_path, then {trace_wave over the
+// block's ray list in LDS, shade_path, compaction of the next rays with __ballot ranks} until the
+// block's 64 pixels finished all their samples, then resolve_pixel; blocks are handed out by one
+// atomic per 64 pixels. There is no device-wide barrier between the stages of different blocks, no
+// global ray queue and no per-round launch, so a small tile (one of 8 GPUs renders 1/8 of the
+// frame: ~340 k rays per round) does not wait for the slowest ray of the whole tile each round, as
+// the multi-kernel pipeline does (measured: 44 % of its full-frame efficiency on a 1/8-height tile).
+// Pixels are identical by construction: the per-pixel code is the same device functions.
+struct FusedArgs {
+    uint32_t* batchHead;   // zeroed before the launch
+    float4* rgba;
+    DevCounters* counters;
+    uint32_t* overflow;    // OVF only
+    uint32_t refill, wSetup, wLeaf, fastLanes;
+};
+
+template <int STACK, bool OVF, bool PIX>
+__global__ __launch_bounds__(RT_BLOCK, 4) void k_render_fused(DevScene sc, PathState ps, FrameParams fp, FusedArgs fa) {
+    __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];
+    __shared__ uint32_t s_list[RT_BLOCK / RT_WAVE][3 * RT_WAVE];
+    const uint32_t wv = threadIdx.x / RT_WAVE;
+    uint32_t* stack = s_stack + wv * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
+    uint32_t* list = s_list[wv];
+    uint32_t* ovf = OVF ? fa.overflow + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x : nullptr;
+    const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
+    const TracePwArgs ta{nullptr, nullptr, nullptr, fa.refill, 0u, fa.wSetup, fa.wLeaf, fa.fastLanes, nullptr, nullptr, fa.counters, nullptr, fa.overflow};
+    WaveTotals wt;
+    uint32_t refTot = 0, pathTot = 0, segTot = 0;
+    const uint32_t nBatches = (fp.nPixels + RT_WAVE - 1) / RT_WAVE;
+
+    for (;;) {
+        uint32_t batch = 0;
+        if (lane_id() == 0) batch = atomicAdd(fa.batchHead, 1u);
+        batch = __shfl(batch, 0, RT_WAVE);
+        if (batch >= nBatches) break;
+        const uint32_t slot = batch * RT_WAVE + lane_id();
+        const bool valid = slot < fp.nPixels;
+        if (valid) init_path(sc, ps, fp, slot);
+        bool alive = valid && fp.samples > 0;
+        unsigned long long mA = __ballot(alive);
+        if (alive) list[lanes_below(mA)] = slot << 2;
+        uint32_t nRays = __popcll(mA);
+        while (nRays) {
+            __threadfence_block();  // the rays written by shade_path / init_path are read by other lanes of this wave
+            trace_wave<STACK, OVF, PIX, false, true>(sc, ps, ta, stack, ovf, ovfStride, list, nRays, wt);
+            __threadfence_block();  // ... and so are the hit records
+            bool nowAlive = false, wantAux = false;
+            uint32_t refRays = 0, nPaths = 0;
+            if (alive) {
+                shade_path(sc, ps, fp, slot, nowAlive, wantAux, refRays, nPaths);
+                segTot++;
+            }
+            alive = nowAlive;
+            refTot += refRays;
+            pathTot += nPaths;
+            mA = __ballot(alive);
+            const unsigned long long mX = __ballot(alive && wantAux);
+            const uint32_t nA = __popcll(mA), nX = __popcll(mX);
+            if (alive) {
+                list[lanes_below(mA)] = (slot << 2) | RAY_MAIN;
+                if (wantAux) {
+                    const uint32_t ra = lanes_below(mX);
+                    list[nA + ra] = (slot << 2) | RAY_NEE;
+                    list[nA + nX + ra] = (slot << 2) | RAY_PROBE;
+                }
+            }
+            nRays = nA + 2u * nX;
+        }
+        __threadfence_block();
+        if (valid) resolve_pixel(ps, fp, fa.rgba, slot);
+    }
+
+    unsigned long long wb = wave_sum_u64(wt.totBox), wtri = wave_sum_u64(wt.totTri);
+    uint32_t wr = wave_sum_u32(wt.totRays), wh = wave_sum_u32(wt.totHits);
+    uint32_t wRef = wave_sum_u32(refTot), wP = wave_sum_u32(pathTot), wS = wave_sum_u32(segTot);
+    if (lane_id() == 0 && (wr | wP | wS)) {
+        atomicAdd(&fa.counters->boxTests, wb);
+        atomicAdd(&fa.counters->triTests, wtri);
+        atomicAdd(&fa.counters->raysTraced, (unsigned long long)wr);
+        atomicAdd(&fa.counters->raysHit, (unsigned long long)wh);
+        atomicAdd(&fa.counters->raysReference, (unsigned long long)wRef);
+        atomicAdd(&fa.counters->paths, (unsigned long long)wP);
+        atomicAdd(&fa.counters->segments, (unsigned long long)wS);
+    }
 }
 
 // ---------------------------------------------------------------- rt_trace_rays support

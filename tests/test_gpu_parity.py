@@ -280,3 +280,24 @@ def test_overflow_stack_beyond_the_lds_part(renderer):
                 _check(renderer.render(pc, W, H), renderer.counters(), ref, rc)
         finally:
             renderer.set_tuning("lds_stack", 24)
+
+
+def test_fused_wave_private_pipeline_matches(renderer):
+    """k_render_fused (each wave runs the whole pipeline on its own 8x8 pixel block) against the oracle and,
+    through it, against the multi-kernel pipeline: pixels and every counter."""
+    cases = [(cornell_scene(True), dict(singleRender=1, sampleLimit=3), 100, 50),
+             (model_scene("bunny.obj", material=5, spheres=True), dict(raysPerPixel=2, frameCount=2), 96, 64),
+             (model_scene("klein_bottle.obj", material=4, scale=0.5, position=(0.0, -0.2, 0.0)), dict(singleRender=1, sampleLimit=2, debug=2, boxCap=300, triangleCap=60), 64, 48)]
+    try:
+        renderer.set_tuning("pipeline", 1)
+        for s, kw, W, H in cases:
+            pc = engine.push_constants(W, H, **kw)
+            _check(*_render_both(renderer, s, pc, W, H))
+        # tiles and zero samples
+        s = cornell_scene(True)
+        pc = engine.push_constants(40, 30, singleRender=1, sampleLimit=2)
+        _check(*_render_both(renderer, s, pc, 40, 30, row0=1, rowStride=3, nRows=len(range(1, 30, 3))))
+        pc = engine.push_constants(16, 8, raysPerPixel=0)
+        _check(*_render_both(renderer, s, pc, 16, 8))
+    finally:
+        renderer.set_tuning("pipeline", 0)

@@ -35,16 +35,17 @@ if args.phase_stats:
 variants = []
 for v in args.variants.split(";"):
     parts = v.split(",")
-    kv = {"trace_variant": int(parts[0][1:])}
+    kv = {"trace_variant": int(parts[0][1:])} if parts[0][0] == "v" else {"pipeline": 1}
     for p in parts[1:]:
         k, x = p.split("=")
         kv[k] = int(x)
     variants.append((v, kv))
 res = {v: [] for v, _ in variants}
 ref_img = ref_cnt = None
+base = {'pipeline': 0, 'trace_variant': 1}
 for rnd in range(args.rounds + 1):
     for name, kv in variants:
-        for k, x in kv.items():
+        for k, x in {**base, **kv}.items():
             r.set_tuning(k, x)
         r.reset_counters()
         r.set_profiling(True)
