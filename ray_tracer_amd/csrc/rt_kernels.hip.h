@@ -1063,7 +1063,7 @@ struct FusedArgs {
 };
 
 template <int STACK, bool OVF, bool PIX>
-__global__ __launch_bounds__(RT_BLOCK, 4) void k_render_fused(DevScene sc, PathState ps, FrameParams fp, FusedArgs fa) {
+__global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(DevScene sc, PathState ps, FrameParams fp, FusedArgs fa) {
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];
     __shared__ uint32_t s_list[RT_BLOCK / RT_WAVE][3 * RT_WAVE];
     const uint32_t wv = threadIdx.x / RT_WAVE;
