@@ -139,12 +139,13 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} ({label}), {W}x{H}, {args.spp} spp/step, bounceLimit 8, "
                                    f"rows interleaved over {world} GPU(s)" + (", RCCL gather per step" if world > 1 else ""),
-                       "scene": args.scene, "assets": label, "width": W, "height": H, "spp_per_step": args.spp},
+                       "scene": args.scene, "assets": label, "width": W, "height": H, "spp_per_step": args.spp,
+                       "pipeline": ["multi-kernel (k_trace_pw + k_shade per round)", "fused (k_render_fused)"][r.last_pipeline()]},
             "unique_mrays_per_s": tot["raysTraced"] / dt / 1e6,
             "spp_per_s": tot["paths"] / (W * H) / dt,
             "paths": tot["paths"], "segments": tot["segments"],
             "box_tests_per_ray": tot["boxTests"] / max(tot["raysTraced"], 1), "tri_tests_per_ray": tot["triTests"] / max(tot["raysTraced"], 1),
-            "roofline": {"bound": "hbm", "kernel": "k_trace", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ["k_trace_pw", "k_render_fused (traversal + shading in one kernel)"][r.last_pipeline()], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes / max(sum_launches, 1.0),
                          "avg_launch_ms": sum_trace_ms / max(sum_launches, 1.0), "launches": sum_launches,

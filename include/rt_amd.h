@@ -278,10 +278,17 @@ int  rt_reset_counters(rt_ctx* ctx);
  * launch count since the last reset (synchronises). */
 int  rt_set_profiling(rt_ctx* ctx, int enabled);
 int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
-/* Performance knobs that never change results: "trace_variant" (0 = one ray per
- * lane, 1 = persistent waves with refill, default), "refill" (idle lanes that
- * trigger a refill, 1..64), "blocks_per_cu" (0 = occupancy query). */
+/* Performance knobs; none of them changes a pixel or a counter.
+ *   "pipeline"       -1 (default) pick by tile size, 0 = multi-kernel wavefront pipeline
+ *                    (k_trace_pw + k_shade per round), 1 = wave-private fused pipeline
+ *                    (k_render_fused: every wave runs the stages on its own 8x8 pixel blocks)
+ *   "fused_below_pixels"  tile size below which -1 picks the fused pipeline
+ *   "trace_variant"  0 = one ray per lane (k_trace), 1 = persistent waves (k_trace_pw)
+ *   "refill", "chunk", "w_setup", "w_leaf", "fast_lanes", "lds_stack", "blocks_per_cu",
+ *   "tile_slots", "phase_stats": traversal scheduling details, see DESIGN.md */
 int  rt_set_tuning(rt_ctx* ctx, const char* key, int value);
+/* pipeline the last rt_render used (0 or 1) */
+int  rt_last_pipeline(const rt_ctx* ctx);
 /* device self-test of the deterministic-math build (must equal RT_SELFTEST_EXPECT) */
 int  rt_device_selftest(rt_ctx* ctx, uint32_t* bitsOut);
 uint32_t rt_host_selftest(void);

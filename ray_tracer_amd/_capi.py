@@ -134,6 +134,7 @@ SYMBOLS = {
     "rt_set_profiling": (C.c_int, [_vp, C.c_int]),
     "rt_get_trace_time_ms": (C.c_int, [_vp, _P(C.c_double), _P(C.c_uint64)]),
     "rt_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "rt_last_pipeline": (C.c_int, [_vp]),
     "rt_device_selftest": (C.c_int, [_vp, _P(C.c_uint32)]),
     "rt_host_selftest": (C.c_uint32, []),
     "rt_measure_copy_bandwidth": (C.c_int, [_vp, C.c_size_t, C.c_int, _P(C.c_double)]),

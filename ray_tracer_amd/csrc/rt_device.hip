@@ -60,7 +60,9 @@ struct rt_ctx {
 
     // tuning (rt_set_tuning)
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
-    int pipeline = 0;       // 0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline (k_render_fused)
+    int pipeline = -1;      // 0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline (k_render_fused), -1 = by tile size
+    int lastPipeline = 0;   // what the last rt_render used
+    uint32_t fusedBelowPixels = 1500000;  // auto: tiles smaller than this use the fused pipeline
     int refill = 8;         // k_trace_pw: idle lanes that trigger a refill
     int chunk = 256;        // k_trace_pw: most queue entries reserved per atomic
     int ldsStackCap = 24;   // k_trace_pw: LDS stack entries per lane (8, 16 or 24); deeper BVHs use the overflow buffer
@@ -607,7 +609,8 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     DevCounters* dc = (DevCounters*)c->counterBuf.p;
     uint32_t* counts = c->q.counts;
 
-    if (c->pipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch
+    c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (nPixels < c->fusedBelowPixels ? 1 : 0);
+    if (c->lastPipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch
         rc = launch_fused(c, fp, fb);
         c->sc = saved;
         return rc;
@@ -763,7 +766,8 @@ int rt_get_trace_time_ms(rt_ctx* c, double* ms, uint64_t* launches) {
 int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     if (!c || !key) return -1;
     std::string k(key);
-    if (k == "pipeline") { if (value < 0 || value > 1) return c->fail("pipeline: 0 or 1"); c->pipeline = value; }
+    if (k == "pipeline") { if (value < -1 || value > 1) return c->fail("pipeline: -1 (auto), 0 or 1"); c->pipeline = value; }
+    else if (k == "fused_below_pixels") { if (value < 0) return c->fail("fused_below_pixels >= 0"); c->fusedBelowPixels = (uint32_t)value; }
     else if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
     else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; }
     else if (k == "lds_stack") { if (value != 8 && value != 16 && value != 24) return c->fail("lds_stack: 8, 16 or 24"); c->ldsStackCap = value; }
@@ -777,6 +781,8 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else return c->fail("unknown tuning key " + k);
     return 0;
 }
+
+int rt_last_pipeline(const rt_ctx* c) { return c ? c->lastPipeline : -1; }
 
 int rt_device_selftest(rt_ctx* c, uint32_t* bitsOut) {
     if (!c || !bitsOut) return -1;

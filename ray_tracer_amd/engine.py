@@ -307,6 +307,10 @@ class Renderer:
     def set_tuning(self, key, value):
         self._check(self._l.rt_set_tuning(self._h, key.encode(), int(value)), "rt_set_tuning")
 
+    def last_pipeline(self):
+        """0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline."""
+        return self._l.rt_last_pipeline(self._h)
+
     def selftest(self):
         b = C.c_uint32()
         self._check(self._l.rt_device_selftest(self._h, C.byref(b)), "rt_device_selftest")

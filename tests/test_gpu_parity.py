@@ -18,6 +18,15 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4  # the north_star tolerance
 
 
+@pytest.fixture(params=[0, 1], ids=["multikernel", "fused"], autouse=True)
+def pipeline(request, renderer):
+    """Every test runs on both pipelines: 0 = k_raygen / k_trace_pw / k_shade / k_resolve launched per round,
+    1 = k_render_fused (each wave runs the same stages on its own 8x8 pixel blocks)."""
+    renderer.set_tuning("pipeline", request.param)
+    yield request.param
+    renderer.set_tuning("pipeline", -1)
+
+
 def _render_both(r, scene, pc, W, H, **tile):
     r.upload_scene(scene)
     r.reset_counters()
@@ -282,14 +291,12 @@ def test_overflow_stack_beyond_the_lds_part(renderer):
             renderer.set_tuning("lds_stack", 24)
 
 
-def test_fused_wave_private_pipeline_matches(renderer):
-    """k_render_fused (each wave runs the whole pipeline on its own 8x8 pixel block) against the oracle and,
-    through it, against the multi-kernel pipeline: pixels and every counter."""
+def test_pipelines_odd_shapes(renderer, pipeline):
+    """Odd widths, strided tiles, heat maps and zero samples on both pipelines."""
     cases = [(cornell_scene(True), dict(singleRender=1, sampleLimit=3), 100, 50),
              (model_scene("bunny.obj", material=5, spheres=True), dict(raysPerPixel=2, frameCount=2), 96, 64),
              (model_scene("klein_bottle.obj", material=4, scale=0.5, position=(0.0, -0.2, 0.0)), dict(singleRender=1, sampleLimit=2, debug=2, boxCap=300, triangleCap=60), 64, 48)]
     try:
-        renderer.set_tuning("pipeline", 1)
         for s, kw, W, H in cases:
             pc = engine.push_constants(W, H, **kw)
             _check(*_render_both(renderer, s, pc, W, H))
@@ -299,5 +306,6 @@ def test_fused_wave_private_pipeline_matches(renderer):
         _check(*_render_both(renderer, s, pc, 40, 30, row0=1, rowStride=3, nRows=len(range(1, 30, 3))))
         pc = engine.push_constants(16, 8, raysPerPixel=0)
         _check(*_render_both(renderer, s, pc, 16, 8))
+        assert renderer.last_pipeline() == pipeline
     finally:
-        renderer.set_tuning("pipeline", 0)
+        pass

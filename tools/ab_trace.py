@@ -42,7 +42,7 @@ for v in args.variants.split(";"):
     variants.append((v, kv))
 res = {v: [] for v, _ in variants}
 ref_img = ref_cnt = None
-base = {'pipeline': 0, 'trace_variant': 1}
+base = {'pipeline': 0, 'trace_variant': 1}  # variants: v0 / v1 (multi-kernel) / fused
 for rnd in range(args.rounds + 1):
     for name, kv in variants:
         for k, x in {**base, **kv}.items():
