@@ -309,3 +309,13 @@ def test_pipelines_odd_shapes(renderer, pipeline):
         assert renderer.last_pipeline() == pipeline
     finally:
         pass
+
+
+def test_long_sample_chains_on_sampled_rows(renderer):
+    """64 serial samples per pixel (the RNG state runs through all of them) on the Sponza stand-in at the
+    BASELINE frame size: eight rows of the 1920x1080 frame, GPU tile vs oracle, bit for bit, with counters."""
+    s, _ = scenes.sponza(0, ntris=40000)
+    W, H = 1920, 1080
+    pc = scenes.sponza_camera(W, H, singleRender=1, sampleLimit=64)
+    tile = dict(row0=67, rowStride=135, nRows=8)
+    _check(*_render_both(renderer, s, pc, W, H, **tile))
