@@ -285,7 +285,10 @@ int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
  *   "fused_below_pixels"  tile size below which -1 picks the fused pipeline
  *   "trace_variant"  0 = one ray per lane (k_trace), 1 = persistent waves (k_trace_pw)
  *   "refill", "chunk", "w_setup", "w_leaf", "fast_lanes", "lds_stack", "blocks_per_cu",
- *   "tile_slots", "phase_stats": traversal scheduling details, see DESIGN.md */
+ *   "tile_slots", "phase_stats": traversal scheduling details, see DESIGN.md
+ *   "batch_pixels"   fused pipeline: pixels per wave-private block, 1..64; 0 (default) = chosen per
+ *                    launch so the blocks divide evenly over the resident waves ("batch_fixed" is
+ *                    the fixed cost per block, in pixel units, that the chooser assumes) */
 int  rt_set_tuning(rt_ctx* ctx, const char* key, int value);
 /* pipeline the last rt_render used (0 or 1) */
 int  rt_last_pipeline(const rt_ctx* ctx);

@@ -72,6 +72,11 @@ struct rt_ctx {
     int numCUs = 256;
     int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase
     int tileSlots = 1;      // slots follow 8x8 pixel blocks instead of rows
+    int batchPixels = 0;    // fused pipeline: pixels per wave-private block (0 = chosen per launch)
+    int batchFixed = 80;    // ... and the fixed part of a block's cost in the chooser, in pixel units
+    int lastBatchPixels = 0;
+    DevBuf waveTimeBuf;     // phase_stats: per-wave start/end clocks of the last k_trace_pw launch
+    size_t waveTimesCount = 0;
     bool pixStats = false;  // this dispatch needs per-pixel box/triangle counts (debug heat maps)
 
     int fail(const std::string& m) { error = m; return -1; }
@@ -175,14 +180,42 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
         if (rc) return rc;
         overflow = (uint32_t*)c->overflowBuf.p;
     }
+    unsigned long long* waveTimes = nullptr;
+    if (c->phaseStats) {
+        c->waveTimesCount = (size_t)blocks * (RT_BLOCK / RT_WAVE);
+        int rc = dev_alloc(c, c->waveTimeBuf, c->waveTimesCount * 16);
+        if (rc) return rc;
+        waveTimes = (unsigned long long*)c->waveTimeBuf.p;
+    }
     TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refill, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes,
-                   ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), overflow};
+                   ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), waveTimes, overflow};
     // per-ray counters are only needed for the pixel heat maps (debug >= 0) and rt_trace_rays
     const bool pix = c->pixStats || ta.perRayBox;
     if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
     else if (pix) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
     else hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
     return 0;
+}
+
+// Pixels per wave-private block of k_render_fused. A wave finishes its block's samples one after the
+// other (the reference's RNG runs on from sample to sample of a pixel), so a tile is done when the wave
+// with the most blocks is: nPixels/64 blocks rarely divide evenly over the resident waves (a 1/8-height
+// 1080p tile is 4050 blocks for 5120 waves), and a slightly smaller block that gives every wave the
+// same number of blocks shortens that critical path. Measured block time ~ (80 + pixels) (drain of the
+// longest ray and the shading step do not shrink with the block); beyond two blocks per wave the
+// dynamic hand-out evens the waves out by itself and whole 8x8 blocks are best.
+uint32_t fused_batch_pixels(const rt_ctx* c, uint32_t nPixels, uint32_t waves) {
+    if (c->batchPixels > 0) return (uint32_t)std::min(c->batchPixels, (int)RT_WAVE);
+    if (((uint64_t)nPixels + RT_WAVE - 1) / RT_WAVE > 2ull * waves) return RT_WAVE;
+    uint32_t best = RT_WAVE;
+    uint64_t bestCost = ~0ull;
+    for (uint32_t b = RT_WAVE; b >= 16; b--) {
+        const uint64_t nb = (nPixels + b - 1) / b;
+        const uint64_t rounds = (nb + waves - 1) / waves;
+        const uint64_t cost = rounds * (uint64_t)((uint32_t)c->batchFixed + b);
+        if (cost < bestCost) { bestCost = cost; best = b; }
+    }
+    return best;
 }
 
 template <int STACK, bool OVF>
@@ -192,7 +225,8 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_render_fused<STACK, OVF, false>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
     }
     const uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
-    const uint32_t nBatches = (fp.nPixels + RT_WAVE - 1) / RT_WAVE;
+    const uint32_t batchPixels = fused_batch_pixels(c, fp.nPixels, resident * (RT_BLOCK / RT_WAVE));
+    const uint32_t nBatches = (fp.nPixels + batchPixels - 1) / batchPixels;
     const uint32_t blocks = std::max(1u, std::min((nBatches + (RT_BLOCK / RT_WAVE) - 1) / (RT_BLOCK / RT_WAVE), resident));
     uint32_t* overflow = nullptr;
     if (OVF) {
@@ -201,7 +235,8 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
         overflow = (uint32_t*)c->overflowBuf.p;
     }
     RT_HIP(c, hipMemsetAsync(c->q.counts + 5, 0, 4, c->stream));
-    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes};
+    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, batchPixels};
+    c->lastBatchPixels = (int)batchPixels;
     if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, fp, fa);
     else hipLaunchKernelGGL((k_render_fused<STACK, OVF, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, fp, fa);
     RT_HIP(c, hipGetLastError());
@@ -331,7 +366,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->sceneBufs) dev_free(b);
     for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->stateBuf,
-                      &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf})
+                      &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf, &c->waveTimeBuf})
         dev_free(*b);
     for (auto& e : c->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->hostCounts) (void)hipHostFree(c->hostCounts);
@@ -480,6 +515,18 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
         leafFirst[c->nodeRemap[nidx]] = b.triCount ? b.index : 0u;
     }
 
+    // ---- the same child pairs, interleaved for packed fp32 math (k_trace_pw / k_render_fused):
+    // pair at even node index p -> 4 float4 at 2p: {L.minx L.miny L.maxx L.maxy} {R.minx R.miny R.maxx R.maxy}
+    // {L.minz L.maxz R.minz R.maxz} {L.W0 R.W0 - -}
+    std::vector<float4> nodesPk(nodes.size(), make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t p = 0; p + 1 < (size_t)devCount; p += 2) {
+        const float4 lo1 = nodes[2 * p], hi1 = nodes[2 * p + 1], lo2 = nodes[2 * p + 2], hi2 = nodes[2 * p + 3];
+        nodesPk[2 * p] = make_float4(lo1.x, lo1.y, hi1.x, hi1.y);
+        nodesPk[2 * p + 1] = make_float4(lo2.x, lo2.y, hi2.x, hi2.y);
+        nodesPk[2 * p + 2] = make_float4(lo1.z, hi1.z, lo2.z, hi2.z);
+        nodesPk[2 * p + 3] = make_float4(lo1.w, lo2.w, 0.f, 0.f);
+    }
+
     // ---- deepest leaf per mesh decides the LDS stack size
     std::vector<RootInfo>& rootOf = c->rootOf;
     rootOf.assign(nNodes, RootInfo{0xffffffffu, 0});
@@ -522,7 +569,7 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
     }
 
     for (auto& b : c->sceneBufs) dev_free(b);
-    c->sceneBufs.assign(4, DevBuf());
+    c->sceneBufs.assign(5, DevBuf());
     int rc;
     if ((rc = upload(c, c->sceneBufs[0], nodes.data(), nodes.size() * sizeof(float4)))) return rc;
     if ((rc = upload(c, c->sceneBufs[1], tpos.data(), tpos.size() * sizeof(float4)))) return rc;
@@ -532,6 +579,8 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
     c->sc.triNrm = (const float4*)c->sceneBufs[2].p;
     if ((rc = upload(c, c->sceneBufs[3], leafFirst.data(), leafFirst.size() * 4))) return rc;
     c->sc.leafFirst = (const uint32_t*)c->sceneBufs[3].p;
+    if ((rc = upload(c, c->sceneBufs[4], nodesPk.data(), nodesPk.size() * sizeof(float4)))) return rc;
+    c->sc.nodesPk = (const float4*)c->sceneBufs[4].p;
     c->sc.nodeCount = devCount;
     c->sc.triCount = nTris;
 
@@ -732,6 +781,20 @@ int rt_get_counters(rt_ctx* c, RtCounters* out) {
         static const char* nm[4] = {"refill", "setup", "interior", "leaf"};
         for (int k = 0; k < 4; k++)
             fprintf(stderr, "[phase_stats] %-8s rounds %12llu lanes %14llu avg active %.1f\n", nm[k], ps[k], ps[4 + k], ps[k] ? (double)ps[4 + k] / ps[k] : 0.0);
+        if (c->waveTimesCount && c->waveTimeBuf.p) {  // the last k_trace_pw launch: when did its waves finish?
+            std::vector<unsigned long long> t(c->waveTimesCount * 2);
+            RT_HIP(c, hipMemcpy(t.data(), c->waveTimeBuf.p, t.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (size_t w = 0; w < c->waveTimesCount; w++) { t0 = std::min(t0, t[2 * w]); t1 = std::max(t1, t[2 * w + 1]); }
+            std::vector<double> end(c->waveTimesCount);
+            double busy = 0;
+            const double span = (double)(t1 - t0);
+            for (size_t w = 0; w < c->waveTimesCount; w++) { end[w] = (t[2 * w + 1] - t0) / span; busy += (t[2 * w + 1] - t[2 * w]) / span; }
+            std::sort(end.begin(), end.end());
+            auto q = [&](double f) { return end[std::min(end.size() - 1, (size_t)(f * end.size()))]; };
+            fprintf(stderr, "[phase_stats] last launch: %zu waves, span %.3f ms (100 MHz clock), mean wave lifetime %.1f %% of it; waves finished by 10/25/50/75/90/99 %% : %.2f %.2f %.2f %.2f %.2f %.2f of the span\n",
+                    c->waveTimesCount, span / 1e5, 100.0 * busy / c->waveTimesCount, q(0.10), q(0.25), q(0.50), q(0.75), q(0.90), q(0.99));
+        }
     }
     return 0;
 }
@@ -776,6 +839,8 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "w_setup") { if (value < 1 || value > 512) return c->fail("w_setup: 1..512"); c->wSetup = value; }
     else if (k == "w_leaf") { if (value < 1 || value > 512) return c->fail("w_leaf: 1..512"); c->wLeaf = value; }
     else if (k == "tile_slots") { c->tileSlots = value != 0; }
+    else if (k == "batch_pixels") { if (value < 0 || value > (int)RT_WAVE) return c->fail("batch_pixels must be 0 (auto) .. 64"); c->batchPixels = value; }
+    else if (k == "batch_fixed") { if (value < 0 || value > 4096) return c->fail("batch_fixed out of range"); c->batchFixed = value; }
     else if (k == "phase_stats") { c->phaseStats = value != 0; }
     else if (k == "blocks_per_cu") { if (value < 0 || value > 8) return c->fail("blocks_per_cu: 0..8"); c->blocksPerCU = value; }
     else return c->fail("unknown tuning key " + k);

@@ -51,6 +51,7 @@
 //   spheres : float4 {center, radius} + uint material
 struct DevScene {
     const float4* nodes;
+    const float4* nodesPk;   // child pairs interleaved for packed math, see rt_upload_scene
     const uint32_t* leafFirst;  // first triangle of a leaf, per node (read only for leaves with > 7 triangles)
     const float4* triPos;
     const float4* triNrm;
@@ -210,6 +211,23 @@ __device__ __forceinline__ float box_intersect(float4 lo, float4 hi, rt_vec3 ro,
     float tFar = rt_min(rt_min(rt_max(ax, bx), rt_max(ay, by)), rt_max(az, bz));
     bool hit = tFar >= tNear && tFar > 0.f;
     return hit ? (tNear > 0.f ? tNear : 0.f) : RT_MISS_DST;
+}
+
+// Both children of a pair from the interleaved layout (DevScene::nodesPk). Same operations and
+// operand order per component as two box_intersect calls; the subtractions and multiplications are
+// written on 2-vectors so that they become v_pk_add_f32 / v_pk_mul_f32 (12 instead of 24 VALU).
+typedef float rt_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void box_intersect_pair(float4 q0, float4 q1, float4 q2, rt_f2 oxy, rt_f2 ixy, rt_f2 zOI, float& d1, float& d2) {
+    const rt_f2 ozz = zOI.xx, izz = zOI.yy;
+    const rt_f2 aL = (rt_f2{q0.x, q0.y} - oxy) * ixy, bL = (rt_f2{q0.z, q0.w} - oxy) * ixy;
+    const rt_f2 aR = (rt_f2{q1.x, q1.y} - oxy) * ixy, bR = (rt_f2{q1.z, q1.w} - oxy) * ixy;
+    const rt_f2 zL = (rt_f2{q2.x, q2.y} - ozz) * izz, zR = (rt_f2{q2.z, q2.w} - ozz) * izz;
+    const float nL = rt_max(rt_max(rt_min(aL.x, bL.x), rt_min(aL.y, bL.y)), rt_min(zL.x, zL.y));
+    const float fL = rt_min(rt_min(rt_max(aL.x, bL.x), rt_max(aL.y, bL.y)), rt_max(zL.x, zL.y));
+    const float nR = rt_max(rt_max(rt_min(aR.x, bR.x), rt_min(aR.y, bR.y)), rt_min(zR.x, zR.y));
+    const float fR = rt_min(rt_min(rt_max(aR.x, bR.x), rt_max(aR.y, bR.y)), rt_max(zR.x, zR.y));
+    d1 = (fL >= nL && fL > 0.f) ? (nL > 0.f ? nL : 0.f) : RT_MISS_DST;
+    d2 = (fR >= nR && fR > 0.f) ? (nR > 0.f ? nR : 0.f) : RT_MISS_DST;
 }
 
 // ---------------------------------------------------------------- leaf references
@@ -383,6 +401,7 @@ struct TracePwArgs {
     uint32_t* perRayTri;
     DevCounters* counters;
     unsigned long long* phaseStats;  // STATS only: [8] rounds and active lanes per phase
+    unsigned long long* waveTimes;   // STATS only: wall_clock64() at start and end of every wave (2 per wave)
     uint32_t* overflow;       // OVF only: stack entries beyond STACK, (maxDepth - STACK) x resident lanes
 };
 
@@ -408,7 +427,10 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                                            size_t ovfStride, const uint32_t* localList, uint32_t n, WaveTotals& wt) {
     uint32_t cur = RT_CUR_IDLE;
     uint32_t id = 0, qidx = 0;
-    rt_vec3 tro = rt_v3(0, 0, 0), trd = tro, inv = tro;  // ray in the current object's space, 1/dir (written by the setup step only)
+    // ray in the current object's space and 1/dir (written by the setup step only); x and y are kept as
+    // 2-vectors so that they sit in aligned register pairs for the packed slab test
+    rt_vec3 trd = rt_v3(0, 0, 0);
+    rt_f2 troXY = {0.f, 0.f}, invXY = {0.f, 0.f}, zOI = {0.f, 0.f};  // zOI = (origin.z, 1/dir.z)
     bool plain = false;    // ray eligible for the identity fast path
     bool atWorld = false;  // tro/trd/inv currently are the world-space ray
     float best = RT_MISS_DST;
@@ -494,7 +516,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     if (PIX) rayTri += jEnd - j; else wt.totTri += jEnd - j;
                     for (; j < jEnd; j++) {
                         const float4 a = sc.triPos[3 * (size_t)j], b = sc.triPos[3 * (size_t)j + 1], c = sc.triPos[3 * (size_t)j + 2];
-                        const TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
+                        const TriHit h = tri_intersect(rt_v3(troXY.x, troXY.y, zOI.x), trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
                         if (h.didHit && h.dst < best) { best = h.dst; bestObj = obj - 1; bestTri = j; }
                     }
                 }
@@ -526,12 +548,13 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     if (general) {
                         const float4 r0 = sc.objInv[3 * obj], r1 = sc.objInv[3 * obj + 1], r2 = sc.objInv[3 * obj + 2];
                         trd = xform_dir_rows(r0, r1, r2, wd);
-                        tro = xform_point_rows(r0, r1, r2, wo);
+                        wo = xform_point_rows(r0, r1, r2, wo);
                     } else {
                         trd = wd;
-                        tro = wo;
                     }
-                    inv = rt_v3(1.f / trd.x, 1.f / trd.y, 1.f / trd.z);
+                    troXY = rt_f2{wo.x, wo.y};
+                    invXY = rt_f2{1.f / trd.x, 1.f / trd.y};
+                    zOI = rt_f2{wo.z, 1.f / trd.z};
                     atWorld = !general;
                     if (general) {
                         cur = nxW;
@@ -548,14 +571,15 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
             // ================= interior step: both children of the pair `cur` =================
             if (STATS) { wt.dbgRounds[2]++; wt.dbgLanes[2] += nI; }
             if ((int32_t)cur >= 0) {
-                const float4* pr = sc.nodes + 2 * (size_t)cur;
-                const float4 lo1 = pr[0], hi1 = pr[1], lo2 = pr[2], hi2 = pr[3];
-                const float d1 = box_intersect(lo1, hi1, tro, inv);
-                const float d2 = box_intersect(lo2, hi2, tro, inv);
+                const float4* pr = sc.nodesPk + 2 * (size_t)cur;
+                const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+                const float2 lk = *(const float2*)(pr + 3);
+                float d1, d2;
+                box_intersect_pair(q0, q1, q2, troXY, invXY, zOI, d1, d2);
                 if (PIX) rayBox += 2; else wt.totBox += 2;
                 const bool nearA = d1 <= d2;
                 const float dNear = nearA ? d1 : d2, dFar = nearA ? d2 : d1;
-                const uint32_t nW = __float_as_uint(nearA ? lo1.w : lo2.w), fW = __float_as_uint(nearA ? lo2.w : lo1.w);
+                const uint32_t nW = __float_as_uint(nearA ? lk.x : lk.y), fW = __float_as_uint(nearA ? lk.y : lk.x);
                 // ready-made word (pair index or leaf reference); kept only if it qualifies
                 if (OVF) {
                     stack[min(sp, (uint32_t)STACK) * RT_WAVE] = fW;
@@ -613,9 +637,13 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
     uint32_t* ovf = OVF ? ta.overflow + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x : nullptr;
     const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
     WaveTotals wt;
+    const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
     trace_wave<STACK, OVF, PIX, STATS, false>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt);
 
     if (STATS && lane_id() == 0) {
+        const size_t w = (size_t)blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;
+        ta.waveTimes[2 * w] = tStart;
+        ta.waveTimes[2 * w + 1] = wall_clock64();
         for (int k = 0; k < 4; k++) {
             atomicAdd(&ta.phaseStats[k], (unsigned long long)wt.dbgRounds[k]);
             atomicAdd(&ta.phaseStats[4 + k], (unsigned long long)wt.dbgLanes[k]);
@@ -1048,8 +1076,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathState ps, FrameParams 
 // ---------------------------------------------------------------- k_render_fused (wave-private pipeline)
 // The same stages, run by each wave on its own 8x8 pixel block: init_path, then {trace_wave over the
 // block's ray list in LDS, shade_path, compaction of the next rays with __ballot ranks} until the
-// block's 64 pixels finished all their samples, then resolve_pixel; blocks are handed out by one
-// atomic per 64 pixels. There is no device-wide barrier between the stages of different blocks, no
+// block's 64 pixels finished all their samples, then resolve_pixel; blocks of `batchPixels` <= 64 consecutive slots are handed out by one
+// atomic each. There is no device-wide barrier between the stages of different blocks, no
 // global ray queue and no per-round launch, so a small tile (one of 8 GPUs renders 1/8 of the
 // frame: ~340 k rays per round) does not wait for the slowest ray of the whole tile each round, as
 // the multi-kernel pipeline does (measured: 44 % of its full-frame efficiency on a 1/8-height tile).
@@ -1060,6 +1088,7 @@ struct FusedArgs {
     DevCounters* counters;
     uint32_t* overflow;    // OVF only
     uint32_t refill, wSetup, wLeaf, fastLanes;
+    uint32_t batchPixels;  // pixels per wave-private block, <= 64 (chosen by the host so the blocks fill the resident waves evenly)
 };
 
 template <int STACK, bool OVF, bool PIX>
@@ -1071,18 +1100,18 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(DevScene sc, PathS
     uint32_t* list = s_list[wv];
     uint32_t* ovf = OVF ? fa.overflow + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x : nullptr;
     const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
-    const TracePwArgs ta{nullptr, nullptr, nullptr, fa.refill, 0u, fa.wSetup, fa.wLeaf, fa.fastLanes, nullptr, nullptr, fa.counters, nullptr, fa.overflow};
+    const TracePwArgs ta{nullptr, nullptr, nullptr, fa.refill, 0u, fa.wSetup, fa.wLeaf, fa.fastLanes, nullptr, nullptr, fa.counters, nullptr, nullptr, fa.overflow};
     WaveTotals wt;
     uint32_t refTot = 0, pathTot = 0, segTot = 0;
-    const uint32_t nBatches = (fp.nPixels + RT_WAVE - 1) / RT_WAVE;
+    const uint32_t nBatches = (fp.nPixels + fa.batchPixels - 1) / fa.batchPixels;
 
     for (;;) {
         uint32_t batch = 0;
         if (lane_id() == 0) batch = atomicAdd(fa.batchHead, 1u);
         batch = __shfl(batch, 0, RT_WAVE);
         if (batch >= nBatches) break;
-        const uint32_t slot = batch * RT_WAVE + lane_id();
-        const bool valid = slot < fp.nPixels;
+        const uint32_t slot = batch * fa.batchPixels + lane_id();
+        const bool valid = lane_id() < fa.batchPixels && slot < fp.nPixels;
         if (valid) init_path(sc, ps, fp, slot);
         bool alive = valid && fp.samples > 0;
         unsigned long long mA = __ballot(alive);
