@@ -353,8 +353,8 @@ int rt_create(int device, rt_ctx** out) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount;
     }
     if (hipHostMalloc((void**)&c->hostCounts, 64, hipHostMallocDefault) != hipSuccess) { delete c; return -6; }
-    if (dev_alloc(c, c->counterBuf, sizeof(DevCounters) + 64) != 0) { delete c; return -7; }
-    (void)hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 64, c->stream);
+    if (dev_alloc(c, c->counterBuf, sizeof(DevCounters) + 128) != 0) { delete c; return -7; }
+    (void)hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 128, c->stream);
     (void)hipStreamSynchronize(c->stream);
     *out = c;
     return 0;
@@ -776,11 +776,13 @@ int rt_get_counters(rt_ctx* c, RtCounters* out) {
     out->raysReference = h.raysReference; out->paths = h.paths; out->segments = h.segments;
     out->traceLaunches = c->traceLaunchesTotal;
     if (c->phaseStats) {
-        unsigned long long ps[8];
+        unsigned long long ps[12];
         RT_HIP(c, hipMemcpy(ps, (char*)c->counterBuf.p + sizeof(DevCounters), sizeof(ps), hipMemcpyDeviceToHost));
         static const char* nm[4] = {"refill", "setup", "interior", "leaf"};
         for (int k = 0; k < 4; k++)
-            fprintf(stderr, "[phase_stats] %-8s rounds %12llu lanes %14llu avg active %.1f\n", nm[k], ps[k], ps[4 + k], ps[k] ? (double)ps[4 + k] / ps[k] : 0.0);
+            fprintf(stderr, "[phase_stats] %-8s rounds %12llu lanes %14llu avg active %.1f  clocks/round %8.0f  share of wave time %.1f %%\n", nm[k], ps[k], ps[4 + k],
+                    ps[k] ? (double)ps[4 + k] / ps[k] : 0.0, ps[k] ? (double)ps[8 + k] / ps[k] : 0.0,
+                    100.0 * ps[8 + k] / std::max(1.0, (double)(ps[8] + ps[9] + ps[10] + ps[11])));
         if (c->waveTimesCount && c->waveTimeBuf.p) {  // the last k_trace_pw launch: when did its waves finish?
             std::vector<unsigned long long> t(c->waveTimesCount * 2);
             RT_HIP(c, hipMemcpy(t.data(), c->waveTimeBuf.p, t.size() * 8, hipMemcpyDeviceToHost));
@@ -802,7 +804,7 @@ int rt_get_counters(rt_ctx* c, RtCounters* out) {
 int rt_reset_counters(rt_ctx* c) {
     if (!c) return -1;
     RT_HIP(c, hipSetDevice(c->device));
-    RT_HIP(c, hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 64, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 128, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     int rc = harvest_events(c);
     c->traceMs = 0.0; c->traceLaunches = 0; c->traceLaunchesTotal = 0;

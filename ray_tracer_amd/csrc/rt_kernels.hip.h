@@ -215,7 +215,9 @@ __device__ __forceinline__ float box_intersect(float4 lo, float4 hi, rt_vec3 ro,
 
 // Both children of a pair from the interleaved layout (DevScene::nodesPk). Same operations and
 // operand order per component as two box_intersect calls; the subtractions and multiplications are
-// written on 2-vectors so that they become v_pk_add_f32 / v_pk_mul_f32 (12 instead of 24 VALU).
+// written on 2-vectors so that they become v_pk_add_f32 / v_pk_mul_f32: 12 instructions instead of
+// 24. On gfx950 that saves issue slots, not ALU time: a packed fp32 op takes as long as its two
+// scalar halves (tools/micro/pk_rate.hip: 0.21 vs 0.38 wave-instructions per clock and SIMD).
 typedef float rt_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void box_intersect_pair(float4 q0, float4 q1, float4 q2, rt_f2 oxy, rt_f2 ixy, rt_f2 zOI, float& d1, float& d2) {
     const rt_f2 ozz = zOI.xx, izz = zOI.yy;
@@ -409,6 +411,7 @@ struct TracePwArgs {
 struct WaveTotals {
     uint32_t totBox = 0, totTri = 0, totRays = 0, totHits = 0;
     uint32_t dbgRounds[4] = {0, 0, 0, 0}, dbgLanes[4] = {0, 0, 0, 0};  // refill, setup, interior, leaf (STATS)
+    unsigned long long dbgCycles[4] = {0, 0, 0, 0};                    // shader clocks spent in rounds of each kind (STATS)
 };
 
 // OVF: the BVH is deeper than STACK; entries beyond the LDS part live in a global overflow buffer
@@ -451,6 +454,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
     };
 
     for (;;) {
+        const unsigned long long tRound = STATS ? clock64() : 0ull;
+        int roundKind = 2;
         const unsigned long long mI = __ballot((int32_t)cur >= 0);
         uint32_t nI = __popcll(mI);
         bool runI = nI >= ta.fastLanes;
@@ -497,6 +502,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
             if (STATS) {
                 if (runL) { wt.dbgRounds[3]++; wt.dbgLanes[3] += nL; }
                 else if (runS) { wt.dbgRounds[1]++; wt.dbgLanes[1] += nS; }
+                roundKind = runI ? 2 : runL ? 3 : runS ? 1 : 0;
             }
 
             if (runL) {
@@ -625,6 +631,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                 cur = RT_CUR_IDLE;
             }
         }
+        if (STATS) wt.dbgCycles[roundKind] += clock64() - tRound;
     }
 
 }
@@ -647,6 +654,7 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
         for (int k = 0; k < 4; k++) {
             atomicAdd(&ta.phaseStats[k], (unsigned long long)wt.dbgRounds[k]);
             atomicAdd(&ta.phaseStats[4 + k], (unsigned long long)wt.dbgLanes[k]);
+            atomicAdd(&ta.phaseStats[8 + k], wt.dbgCycles[k]);
         }
     }
     unsigned long long wb = wave_sum_u64(wt.totBox), wtri = wave_sum_u64(wt.totTri);
