@@ -7,11 +7,18 @@
 // "port" CPU baseline of bench.py. Only tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg may load it; the product never does.
 //
-// PARITY STATUS: "parity unpinned" by the reference. The reference has no
-// tests, golden vectors or recorded renders for this path,
-// and its shader cannot be compiled here (no GLSL compiler, no Vulkan). What
-// pins this file is (1) the RNG known-answer values derived from the formula
-// of raytrace.comp:158-163, (2) the std140 layout sizes (A14),
+// PARITY STATUS: bit-level "parity unpinned": the reference has no tests or
+// golden vectors for this path and its shader cannot be
+// compiled here (no GLSL compiler, no Vulkan). Image-level it IS pinned, to
+// the one output of the reference whose parameters are known — the screenshot
+// renders/importance_sampling/0_1-NEE2.png (default Cornell scene, single
+// render, 100 samples, bounce limit 5, all readable in its ImGui panel):
+// tests/test_reference_render.py recovers the 1728x1117 render from it and
+// finds the same silhouette and light edges to the pixel, the same radiometry
+// per region and channel within 1.5 %, the same per-pixel noise level, and
+// noise that follows this code's frameCount-0 RNG streams and no other seed.
+// Besides that: (1) the RNG known-answer values derived from the formula of
+// raytrace.comp:158-163, (2) the std140 layout sizes (A14),
 // (3) line-by-line review against the shader (citations below), and
 // (4) scene invariants of the default Cornell box (51 triangles, 153 points,
 // 9 objects). GLSL built-ins come from include/rt_det_math.h (GLSL 4.50 spec
