@@ -283,6 +283,8 @@ int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
  *                    (k_trace_pw + k_shade per round), 1 = wave-private fused pipeline
  *                    (k_render_fused: every wave runs the stages on its own 8x8 pixel blocks)
  *   "fused_below_pixels"  tile size below which -1 picks the fused pipeline
+ *   "fused_below_box_tests"  ... and box tests per ray (measured on the context's earlier dispatches of
+ *                    the scene, copied back without waiting) below which it does so at any size
  *   "trace_variant"  0 = one ray per lane (k_trace), 1 = persistent waves (k_trace_pw)
  *   "refill", "chunk", "w_setup", "w_leaf", "fast_lanes", "lds_stack", "blocks_per_cu",
  *   "tile_slots", "phase_stats": traversal scheduling details, see DESIGN.md

@@ -63,6 +63,13 @@ struct rt_ctx {
     int pipeline = -1;      // 0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline (k_render_fused), -1 = by tile size
     int lastPipeline = 0;   // what the last rt_render used
     uint32_t fusedBelowPixels = 1500000;  // auto: tiles smaller than this use the fused pipeline
+    uint32_t fusedBelowBoxTests = 90;     // auto: ... and so do scenes whose rays are short (box tests per ray, measured)
+    // box tests per ray of this scene, from counter snapshots copied back asynchronously after each dispatch
+    DevCounters* snap = nullptr;          // pinned
+    hipEvent_t snapEvent = nullptr;
+    bool snapPending = false;
+    unsigned long long snapBox = 0, snapRays = 0;  // counters at the previous snapshot
+    double boxPerRay = -1.0;              // < 0: not measured yet
     int refill = 8;         // k_trace_pw: idle lanes that trigger a refill
     int chunk = 256;        // k_trace_pw: most queue entries reserved per atomic
     int ldsStackCap = 24;   // k_trace_pw: LDS stack entries per lane (8, 16 or 24); deeper BVHs use the overflow buffer
@@ -353,6 +360,8 @@ int rt_create(int device, rt_ctx** out) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount;
     }
     if (hipHostMalloc((void**)&c->hostCounts, 64, hipHostMallocDefault) != hipSuccess) { delete c; return -6; }
+    if (hipHostMalloc((void**)&c->snap, sizeof(DevCounters), hipHostMallocDefault) != hipSuccess) { delete c; return -6; }
+    if (hipEventCreateWithFlags(&c->snapEvent, hipEventDisableTiming) != hipSuccess) { delete c; return -6; }
     if (dev_alloc(c, c->counterBuf, sizeof(DevCounters) + 128) != 0) { delete c; return -7; }
     (void)hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 128, c->stream);
     (void)hipStreamSynchronize(c->stream);
@@ -370,6 +379,8 @@ void rt_destroy(rt_ctx* c) {
         dev_free(*b);
     for (auto& e : c->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->hostCounts) (void)hipHostFree(c->hostCounts);
+    if (c->snap) (void)hipHostFree(c->snap);
+    if (c->snapEvent) (void)hipEventDestroy(c->snapEvent);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -460,6 +471,8 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
     if (!c || !s) return -1;
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->snapPending) { c->snapBox = c->snap->boxTests; c->snapRays = c->snap->raysTraced; c->snapPending = false; }
+    c->boxPerRay = -1.0;  // a new scene: its ray cost is not known yet
     const uint32_t nNodes = s->bvhNodeCount, nTris = s->triangleCount;
 
     // ---- mesh segmentation: every distinct object.bvhIndex starts a mesh
@@ -598,6 +611,30 @@ int rt_sync(rt_ctx* c) {
     return harvest_events(c);
 }
 
+}  // extern "C"
+
+namespace {
+// Fold in the counter snapshot of an earlier dispatch if its copy has arrived (never waits).
+void poll_ray_cost(rt_ctx* c) {
+    if (!c->snapPending || hipEventQuery(c->snapEvent) != hipSuccess) return;
+    c->snapPending = false;
+    const unsigned long long box = c->snap->boxTests, rays = c->snap->raysTraced;
+    if (rays > c->snapRays && box >= c->snapBox && rays - c->snapRays > 100000ull)
+        c->boxPerRay = (double)(box - c->snapBox) / (double)(rays - c->snapRays);
+    c->snapBox = box;
+    c->snapRays = rays;
+}
+// Queue the next snapshot behind the dispatch just enqueued.
+void request_ray_cost(rt_ctx* c) {
+    if (c->snapPending) return;
+    if (hipMemcpyAsync(c->snap, c->counterBuf.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return;
+    if (hipEventRecord(c->snapEvent, c->stream) != hipSuccess) return;
+    c->snapPending = true;
+}
+}  // namespace
+
+extern "C" {
+
 int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t height, uint32_t row0, uint32_t rowStride,
               uint32_t nRows, float* d_rgba) {
     if (!c || !pc) return -1;
@@ -658,10 +695,15 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     DevCounters* dc = (DevCounters*)c->counterBuf.p;
     uint32_t* counts = c->q.counts;
 
-    c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (nPixels < c->fusedBelowPixels ? 1 : 0);
+    // Both pipelines give the same bits; which one is faster depends on how much a wave has to do per pixel. Small tiles
+    // and scenes with short rays (few box tests per ray, measured on this context's earlier dispatches) go to the fused one.
+    poll_ray_cost(c);
+    const bool shortRays = c->boxPerRay >= 0.0 && c->boxPerRay < (double)c->fusedBelowBoxTests;
+    c->lastPipeline = c->pipeline >= 0 ? c->pipeline : ((nPixels < c->fusedBelowPixels || shortRays) ? 1 : 0);
     if (c->lastPipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch
         rc = launch_fused(c, fp, fb);
         c->sc = saved;
+        if (!rc) request_ray_cost(c);
         return rc;
     }
     hipLaunchKernelGGL(k_raygen, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, c->q, fp);
@@ -702,6 +744,7 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     hipLaunchKernelGGL(k_resolve, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->ps, fp, fb);
     RT_HIP(c, hipGetLastError());
     c->sc = saved;
+    request_ray_cost(c);
     return 0;
 }
 
@@ -806,6 +849,8 @@ int rt_reset_counters(rt_ctx* c) {
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 128, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->snapPending = false;
+    c->snapBox = 0; c->snapRays = 0;
     int rc = harvest_events(c);
     c->traceMs = 0.0; c->traceLaunches = 0; c->traceLaunchesTotal = 0;
     return rc;
@@ -832,6 +877,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     if (!c || !key) return -1;
     std::string k(key);
     if (k == "pipeline") { if (value < -1 || value > 1) return c->fail("pipeline: -1 (auto), 0 or 1"); c->pipeline = value; }
+    else if (k == "fused_below_box_tests") { if (value < 0) return c->fail("fused_below_box_tests >= 0"); c->fusedBelowBoxTests = (uint32_t)value; }
     else if (k == "fused_below_pixels") { if (value < 0) return c->fail("fused_below_pixels >= 0"); c->fusedBelowPixels = (uint32_t)value; }
     else if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
     else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; }

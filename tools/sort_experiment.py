@@ -119,6 +119,14 @@ def main():
             r.set_tuning("phase_stats", 0)
         print(f"bounce {k}: {len(o)} rays  natural {ms:7.3f} ms  box/ray {c['boxTests'] / len(o):.1f} tri/ray {c['triTests'] / len(o):.1f}", flush=True)
         if k > 0:
+            if not a.phase_stats:
+                # upper bound of longest-ray-first scheduling: order by the cost this very batch was measured to have
+                hn = engine.hits_to_numpy(hits)
+                cost = hn["boxTests"].astype(np.int64) + hn["triTests"]
+                for nm, idx in (("cost descending", np.argsort(-cost, kind="stable")), ("cost ascending", np.argsort(cost, kind="stable")),
+                                ("longest 10 % first", np.argsort(-(cost >= np.percentile(cost, 90)).astype(np.int64), kind="stable"))):
+                    ms2, _ = timed(r, o[idx], d[idx])
+                    print(f"          {nm:24s} {ms2:7.3f} ms  ({ms / ms2:.2f}x)", flush=True)
             for kind in (() if a.phase_stats else ("octant", "origin", "octant_origin", "origin_octant", "random")):
                 idx = np.argsort(keys(o, d, kind, a.grid), kind="stable")
                 if a.phase_stats:
