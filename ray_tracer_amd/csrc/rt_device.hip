@@ -144,18 +144,10 @@ int ensure_state(rt_ctx* c, uint32_t nPixels) {
     const int nF4 = 13, nU1 = 2;
     int rc = dev_alloc(c, c->stateBuf, stride4 * nF4 + stride1 * nU1);
     if (rc) return rc;
-    char* base = (char*)c->stateBuf.p;
-    int k = 0;
-    auto next4 = [&]() { return (float4*)(base + stride4 * (k++)); };
     PathState& ps = c->ps;
-    ps.rayO = next4(); ps.rayD = next4();
-    ps.auxO = next4(); ps.auxDL = next4(); ps.auxDC = next4();
-    for (int i = 0; i < 3; i++) ps.hit[i] = next4();
-    ps.att = next4(); ps.total = next4(); ps.direct = next4();
-    ps.pendAlbedo = next4(); ps.accum = next4();
-    if (k != nF4) return c->fail("internal: path state array count");
-    ps.statBox = (uint32_t*)(base + stride4 * nF4);
-    ps.statTri = (uint32_t*)(base + stride4 * nF4 + stride1);
+    ps.base = (float4*)c->stateBuf.p;
+    ps.pitch = (uint32_t)(stride4 / 16);
+    ps.pitchStat = (uint32_t)(stride1 / 4);
 
     // queues: 2 x active (n) + 2 x rays (3n) + 4 counters
     const size_t qa = (((size_t)nPixels * 4) + 255) & ~(size_t)255;
@@ -244,8 +236,9 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
     RT_HIP(c, hipMemsetAsync(c->q.counts + 5, 0, 4, c->stream));
     FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, batchPixels};
     c->lastBatchPixels = (int)batchPixels;
-    if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, fp, fa);
-    else hipLaunchKernelGGL((k_render_fused<STACK, OVF, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, fp, fa);
+    const FusedKernArgs ka{c->sc, c->ps, fp, fa};
+    if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
+    else hipLaunchKernelGGL((k_render_fused<STACK, OVF, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
     RT_HIP(c, hipGetLastError());
     return 0;
 }
@@ -787,8 +780,8 @@ int rt_trace_rays(rt_ctx* c, uint32_t n, const float* origins, const float* dirs
         ho[i] = make_float4(origins[(size_t)i * 3], origins[(size_t)i * 3 + 1], origins[(size_t)i * 3 + 2], 0.f);
         hd[i] = make_float4(dirs[(size_t)i * 3], dirs[(size_t)i * 3 + 1], dirs[(size_t)i * 3 + 2], 0.f);
     }
-    RT_HIP(c, hipMemcpyAsync(c->ps.rayO, ho.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-    RT_HIP(c, hipMemcpyAsync(c->ps.rayD, hd.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(c->ps.rayO(), ho.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipMemcpyAsync(c->ps.rayD(), hd.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     size_t need = (size_t)n * 8 + (size_t)n * sizeof(RtHit) + 256;
     if ((rc = dev_alloc(c, c->scratchBuf, need))) return rc;
@@ -797,8 +790,8 @@ int rt_trace_rays(rt_ctx* c, uint32_t n, const float* origins, const float* dirs
     RtHit* dh = (RtHit*)((char*)c->scratchBuf.p + (((size_t)n * 8 + 255) & ~(size_t)255));
     c->hostCounts[0] = n; c->hostCounts[1] = 0; c->hostCounts[2] = 0; c->hostCounts[3] = 0; c->hostCounts[4] = 0;
     RT_HIP(c, hipMemcpyAsync(c->q.counts, c->hostCounts, 20, hipMemcpyHostToDevice, c->stream));
-    RT_HIP(c, hipMemsetAsync(c->ps.statBox, 0, (size_t)n * 4, c->stream));
-    RT_HIP(c, hipMemsetAsync(c->ps.statTri, 0, (size_t)n * 4, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->ps.statBox(), 0, (size_t)n * 4, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->ps.statTri(), 0, (size_t)n * 4, c->stream));
     hipLaunchKernelGGL(k_seed_rays, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, n);
     TraceArgs ta{nullptr, c->q.counts, prb, prt, (DevCounters*)c->counterBuf.p};
     if ((rc = launch_trace(c, n, ta))) return rc;

@@ -70,20 +70,26 @@ enum { RAY_MAIN = 0, RAY_NEE = 1, RAY_PROBE = 2 };
 // 16-byte records per slot: a path touches its state through a dozen dwordx4
 // accesses instead of ~85 dword accesses (k_shade is bound by the number of
 // memory instructions in flight, not by bytes).
+// One base pointer and the array pitch instead of fifteen pointers: the kernels that shade and traverse in one
+// (k_render_fused) are short of scalar registers, and an array's address is one scalar multiply-add away.
 struct PathState {
-    float4* rayO;        // main ray origin            | w: misWeight (raytrace.comp:487)
-    float4* rayD;        // main ray direction         | w: RNG state bits (:564)
-    float4* auxO;        // origin of the probe rays   | w: max(0, dot(n, lightSample))          (:460)
-    float4* auxDL;       // NEE direction              | w: cosineHemispherePDF(n, lightSample)  (:448)
-    float4* auxDC;       // cosine-sample direction    | w: cosineHemispherePDF(n, cosineSample) (:454)
-    float4* hit[3];      // per ray kind: {dst, object bits, triangle bits, -}
-    float4* att;         // attenuation                | w: bounce index j, bit 31 = NEE results pending
-    float4* total;       // totalColor                 | w: samples finished for this pixel
-    float4* direct;      // directLight
-    float4* pendAlbedo;  // albedo of the previous diffuse hit
-    float4* accum;       // sum of trace() over the pixel's samples (:572)
-    uint32_t* statBox;   // stats[0] of the pixel (main-path traversals only)
-    uint32_t* statTri;   // stats[1]
+    float4* base;
+    uint32_t pitch;       // float4 elements between consecutive arrays (>= slots, 256-byte multiple)
+    uint32_t pitchStat;   // uint32 elements between statBox and statTri
+    __host__ __device__ __forceinline__ float4* arr(uint32_t k) const { return base + (size_t)k * pitch; }
+    __host__ __device__ __forceinline__ float4* rayO() const { return arr(0); }        // main ray origin            | w: misWeight (raytrace.comp:487)
+    __host__ __device__ __forceinline__ float4* rayD() const { return arr(1); }        // main ray direction         | w: RNG state bits (:564)
+    __host__ __device__ __forceinline__ float4* auxO() const { return arr(2); }        // origin of the probe rays   | w: max(0, dot(n, lightSample))          (:460)
+    __host__ __device__ __forceinline__ float4* auxDL() const { return arr(3); }       // NEE direction              | w: cosineHemispherePDF(n, lightSample)  (:448)
+    __host__ __device__ __forceinline__ float4* auxDC() const { return arr(4); }       // cosine-sample direction    | w: cosineHemispherePDF(n, cosineSample) (:454)
+    __host__ __device__ __forceinline__ float4* hit(uint32_t kind) const { return arr(5 + kind); }  // per ray kind: {dst, object bits, triangle bits, -}
+    __host__ __device__ __forceinline__ float4* att() const { return arr(8); }         // attenuation                | w: bounce index j, bit 31 = NEE results pending
+    __host__ __device__ __forceinline__ float4* total() const { return arr(9); }       // totalColor                 | w: samples finished for this pixel
+    __host__ __device__ __forceinline__ float4* direct() const { return arr(10); }     // directLight
+    __host__ __device__ __forceinline__ float4* pendAlbedo() const { return arr(11); } // albedo of the previous diffuse hit
+    __host__ __device__ __forceinline__ float4* accum() const { return arr(12); }      // sum of trace() over the pixel's samples (:572)
+    __host__ __device__ __forceinline__ uint32_t* statBox() const { return (uint32_t*)arr(13); }             // stats[0] of the pixel (main-path traversals only)
+    __host__ __device__ __forceinline__ uint32_t* statTri() const { return (uint32_t*)arr(13) + pitchStat; } // stats[1]
 };
 
 struct Queues {
@@ -276,8 +282,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
         slot = id >> 2;
         kind = id & 3u;
         rt_vec3 ro, rd;
-        if (kind == RAY_MAIN) { ro = f4xyz(ps.rayO[slot]); rd = f4xyz(ps.rayD[slot]); }
-        else { ro = f4xyz(ps.auxO[slot]); rd = f4xyz(kind == RAY_NEE ? ps.auxDL[slot] : ps.auxDC[slot]); }
+        if (kind == RAY_MAIN) { ro = f4xyz(ps.rayO()[slot]); rd = f4xyz(ps.rayD()[slot]); }
+        else { ro = f4xyz(ps.auxO()[slot]); rd = f4xyz(kind == RAY_NEE ? ps.auxDL()[slot] : ps.auxDC()[slot]); }
 
         float best = RT_MISS_DST;
         uint32_t bestObj = RT_HIT_NONE, bestTri = 0;
@@ -345,8 +351,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
             }
         }
 
-        ps.hit[kind][slot] = make_float4(best, __uint_as_float(bestObj), __uint_as_float(bestTri), 0.f);
-        if (kind == RAY_MAIN && ps.statBox) { ps.statBox[slot] += nBox; ps.statTri[slot] += nTri; }
+        ps.hit(kind)[slot] = make_float4(best, __uint_as_float(bestObj), __uint_as_float(bestTri), 0.f);
+        if (kind == RAY_MAIN && ps.statBox()) { ps.statBox()[slot] += nBox; ps.statTri()[slot] += nTri; }
         if (ta.perRayBox) { ta.perRayBox[gid] = nBox; ta.perRayTri[gid] = nTri; }
         didHit = bestObj != RT_HIT_NONE;
     }
@@ -534,11 +540,11 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                 if (cur - RT_CUR_INIT <= RT_CUR_SETUP - RT_CUR_INIT) {
                     const uint32_t slot = id >> 2, kind = id & 3u;
                     rt_vec3 wo, wd;
-                    if (kind == RAY_MAIN) { wo = f4xyz(ps.rayO[slot]); wd = f4xyz(ps.rayD[slot]); }
-                    else { wo = f4xyz(ps.auxO[slot]); wd = f4xyz(kind == RAY_NEE ? ps.auxDL[slot] : ps.auxDC[slot]); }
+                    if (kind == RAY_MAIN) { wo = f4xyz(ps.rayO()[slot]); wd = f4xyz(ps.rayD()[slot]); }
+                    else { wo = f4xyz(ps.auxO()[slot]); wd = f4xyz(kind == RAY_NEE ? ps.auxDL()[slot] : ps.auxDC()[slot]); }
                     if (cur == RT_CUR_INIT) {
                         // the ray's creator already ran the sphere loop (sphere_seed)
-                        const float4 seed = ps.hit[kind][slot];
+                        const float4 seed = ps.hit(kind)[slot];
                         best = seed.x; bestObj = __float_as_uint(seed.y); bestTri = 0;
                         // finite and non-zero direction, finite origin without negative zeros
                         const uint32_t E = 0x7f800000u, M = 0x7fffffffu;
@@ -621,8 +627,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
             }
             if (cur == RT_CUR_DONE) {
                 const uint32_t slot = id >> 2, kind = id & 3u;
-                ps.hit[kind][slot] = make_float4(best, __uint_as_float(bestObj), __uint_as_float(bestTri), 0.f);
-                if (PIX && kind == RAY_MAIN) { ps.statBox[slot] += rayBox; ps.statTri[slot] += rayTri; }
+                ps.hit(kind)[slot] = make_float4(best, __uint_as_float(bestObj), __uint_as_float(bestTri), 0.f);
+                if (PIX && kind == RAY_MAIN) { ps.statBox()[slot] += rayBox; ps.statTri()[slot] += rayTri; }
                 if (PIX) {
                     if (ta.perRayBox) { ta.perRayBox[qidx] = rayBox; ta.perRayTri[qidx] = rayTri; }
                     wt.totBox += rayBox; wt.totTri += rayTri;
@@ -779,16 +785,16 @@ __device__ __forceinline__ void init_path(const DevScene& sc, const PathState& p
     uint32_t gx, gy;
     uint32_t krow;
     slot_to_pixel(fp, slot, gx, gy, krow);
-    ps.rayO[slot] = make_float4(fp.camPos[0], fp.camPos[1], fp.camPos[2], 1.f);                          // misWeight = 1
+    ps.rayO()[slot] = make_float4(fp.camPos[0], fp.camPos[1], fp.camPos[2], 1.f);                          // misWeight = 1
     const rt_vec3 pd = primary_dir(fp, gx, gy);
-    ps.rayD[slot] = mk4u(pd, gy * fp.width + gx + fp.startingSeed);                                   // RNG seed (:564)
-    ps.hit[RAY_MAIN][slot] = sphere_seed(sc, rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]), pd);
-    ps.att[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));                                   // j = 0
-    ps.total[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));                                 // sample 0
-    ps.direct[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-    ps.accum[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-    ps.statBox[slot] = 0;
-    ps.statTri[slot] = 0;
+    ps.rayD()[slot] = mk4u(pd, gy * fp.width + gx + fp.startingSeed);                                   // RNG seed (:564)
+    ps.hit(RAY_MAIN)[slot] = sphere_seed(sc, rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]), pd);
+    ps.att()[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));                                   // j = 0
+    ps.total()[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));                                 // sample 0
+    ps.direct()[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ps.accum()[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ps.statBox()[slot] = 0;
+    ps.statTri()[slot] = 0;
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void k_raygen(DevScene sc, PathState ps, Queues q, FrameParams fp) {
@@ -817,8 +823,8 @@ struct ShadeArgs {
 __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& ps, const FrameParams& fp, uint32_t slot, bool& alive,
                                            bool& wantAux, uint32_t& refRays, uint32_t& nPaths) {
     rt_vec3 auxOrigin = rt_v3(0, 0, 0), auxL = auxOrigin, auxC = auxOrigin;  // probe rays of this bounce (diffuse only)
-    const float4 sO = ps.rayO[slot], sD = ps.rayD[slot], sA = ps.att[slot], sT = ps.total[slot], sDi = ps.direct[slot];
-    const float4 hM = ps.hit[RAY_MAIN][slot];
+    const float4 sO = ps.rayO()[slot], sD = ps.rayD()[slot], sA = ps.att()[slot], sT = ps.total()[slot], sDi = ps.direct()[slot];
+    const float4 hM = ps.hit(RAY_MAIN)[slot];
     rt_vec3 ro = f4xyz(sO), rd = f4xyz(sD);
     rt_vec3 att = f4xyz(sA), total = f4xyz(sT), direct = f4xyz(sDi);
     float misW = sO.w;
@@ -840,8 +846,8 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
             // finish diffuseBRDF of the previous bounce (:443-460); its three
             // scene queries were the NEE ray (once for :443 and :447) and the
             // cosine probe (:453)
-            const float4 hL = ps.hit[RAY_NEE][slot], hC = ps.hit[RAY_PROBE][slot];
-            const float4 aO = ps.auxO[slot], aL = ps.auxDL[slot], aC = ps.auxDC[slot];
+            const float4 hL = ps.hit(RAY_NEE)[slot], hC = ps.hit(RAY_PROBE)[slot];
+            const float4 aO = ps.auxO()[slot], aL = ps.auxDL()[slot], aC = ps.auxDC()[slot];
             float tL = hL.x, tC = hC.x;
             uint32_t oL = __float_as_uint(hL.y), oC = __float_as_uint(hC.y);
             rt_vec3 dL = f4xyz(aL), dC = f4xyz(aC);
@@ -855,7 +861,7 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
             float realCosinePDF = aC.w;
             float misWeight2 = realCosinePDF * realCosinePDF / (lightPDF * lightPDF + realCosinePDF * realCosinePDF);
             if (rt_isnan(misWeight2)) misWeight2 = 0.f;
-            rt_vec3 albedo = f4xyz(ps.pendAlbedo[slot]);
+            rt_vec3 albedo = f4xyz(ps.pendAlbedo()[slot]);
             rt_vec3 dl = rt_scale(rt_v3(lmE.x, lmE.y, lmE.z), lmE.w);
             float k = (realLightPDF == 0.f) ? 0.f : misWeight1 / realLightPDF;
             rt_vec3 f = rt_scale(rt_scale(rt_scale(albedo, RT_INV_PI), aO.w), k);
@@ -925,10 +931,10 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
                 sampledDir = cosineSample;
 
                 auxOrigin = origin; auxL = lightSample; auxC = cosineSample;
-                ps.auxO[slot] = mk4(origin, rt_max(0.f, rt_dot(hit.normal, lightSample)));
-                ps.auxDL[slot] = mk4(lightSample, rt_max(0.f, rt_dot(lightSample, hit.normal) * RT_INV_PI));
-                ps.auxDC[slot] = mk4(cosineSample, realCosinePDF);
-                ps.pendAlbedo[slot] = mk4(albedo, 0.f);
+                ps.auxO()[slot] = mk4(origin, rt_max(0.f, rt_dot(hit.normal, lightSample)));
+                ps.auxDL()[slot] = mk4(lightSample, rt_max(0.f, rt_dot(lightSample, hit.normal) * RT_INV_PI));
+                ps.auxDC()[slot] = mk4(cosineSample, realCosinePDF);
+                ps.pendAlbedo()[slot] = mk4(albedo, 0.f);
             }
             att = rt_mul(att, radiance);
 
@@ -956,10 +962,10 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
 
     if (done) {
         nPaths = 1;
-        float4 acc = ps.accum[slot];
+        float4 acc = ps.accum()[slot];
         if (zeroed) total = rt_v3(0.f, 0.f, 0.f);
         const rt_vec3 sum = rt_add(f4xyz(acc), total);
-        ps.accum[slot] = mk4(sum, 0.f);
+        ps.accum()[slot] = mk4(sum, 0.f);
         samplesDone++;
         if (samplesDone < fp.samples) {
             // next sample of this pixel: same primary ray, RNG state runs on (:571-573)
@@ -980,16 +986,16 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
     }
 
     if (alive) {
-        ps.hit[RAY_MAIN][slot] = sphere_seed(sc, ro, rd);
+        ps.hit(RAY_MAIN)[slot] = sphere_seed(sc, ro, rd);
         if (wantAux) {
-            ps.hit[RAY_NEE][slot] = sphere_seed(sc, auxOrigin, auxL);
-            ps.hit[RAY_PROBE][slot] = sphere_seed(sc, auxOrigin, auxC);
+            ps.hit(RAY_NEE)[slot] = sphere_seed(sc, auxOrigin, auxL);
+            ps.hit(RAY_PROBE)[slot] = sphere_seed(sc, auxOrigin, auxC);
         }
-        ps.rayO[slot] = mk4(ro, misW);
-        ps.rayD[slot] = mk4u(rd, state);
-        ps.att[slot] = mk4u(att, j | (wantAux ? 0x80000000u : 0u));
-        ps.total[slot] = mk4u(total, samplesDone);
-        ps.direct[slot] = mk4(direct, 0.f);
+        ps.rayO()[slot] = mk4(ro, misW);
+        ps.rayD()[slot] = mk4u(rd, state);
+        ps.att()[slot] = mk4u(att, j | (wantAux ? 0x80000000u : 0u));
+        ps.total()[slot] = mk4u(total, samplesDone);
+        ps.direct()[slot] = mk4(direct, 0.f);
     }
 }
 
@@ -1051,7 +1057,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
 // raytrace.comp:574-593. `rgba` holds the previous frame when progressive
 // (kept in fp32 instead of the reference's 8-bit image).
 __device__ __forceinline__ void resolve_pixel(const PathState& ps, const FrameParams& fp, float4* rgba, uint32_t slot) {
-    rt_vec3 out = f4xyz(ps.accum[slot]);
+    rt_vec3 out = f4xyz(ps.accum()[slot]);
     float fs = (float)fp.samples;
     out = rt_v3(out.x / fs, out.y / fs, out.z / fs);
     float weight = 1.f / ((float)fp.frameCount + 1.f);
@@ -1063,7 +1069,7 @@ __device__ __forceinline__ void resolve_pixel(const PathState& ps, const FramePa
     rt_vec3 fin = fp.progressive ? blended : out;
     if (rt_isnan(fin.x) || rt_isnan(fin.y) || rt_isnan(fin.z) || rt_isinf(fin.x) || rt_isinf(fin.y) || rt_isinf(fin.z))
         fin = rt_v3(1.f, 0.f, 1.f);
-    float s0 = (float)ps.statBox[slot], s1 = (float)ps.statTri[slot];
+    float s0 = (float)ps.statBox()[slot], s1 = (float)ps.statTri()[slot];
     float boxCap = (float)fp.boxCap, triCap = (float)fp.triCap;
     if (fp.debug == 0) {
         fin = s0 > boxCap ? rt_v3(1.f, 0.f, 0.f) : rt_v3(s0 / boxCap, s0 / boxCap, s0 / boxCap);
@@ -1099,8 +1105,30 @@ struct FusedArgs {
     uint32_t batchPixels;  // pixels per wave-private block, <= 64 (chosen by the host so the blocks fill the resident waves evenly)
 };
 
+// The kernel-argument segment as memory the compiler knows nothing about: loads through the returned pointer
+// cannot be hoisted above the call, so values that are only needed now and then are fetched (scalar loads,
+// scalar cache) where they are used instead of occupying scalar registers across the traversal loop.
+template <typename T>
+__device__ __forceinline__ const T* opaque_kernarg() {
+    unsigned long long v = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(v));
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const T*)(((unsigned long long)hi << 32) | lo);
+}
+
+struct FusedKernArgs {  // the whole kernel-argument segment, so that it can be addressed as memory
+    DevScene sc;
+    PathState ps;
+    FrameParams fp;
+    FusedArgs fa;
+};
+
 template <int STACK, bool OVF, bool PIX>
-__global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(DevScene sc, PathState ps, FrameParams fp, FusedArgs fa) {
+__global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) {
+    const DevScene& sc = ka.sc;
+    const PathState& ps = ka.ps;
+    const FrameParams& fp = ka.fp;
+    const FusedArgs& fa = ka.fa;
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];
     __shared__ uint32_t s_list[RT_BLOCK / RT_WAVE][3 * RT_WAVE];
     const uint32_t wv = threadIdx.x / RT_WAVE;
@@ -1120,7 +1148,13 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(DevScene sc, PathS
         if (batch >= nBatches) break;
         const uint32_t slot = batch * fa.batchPixels + lane_id();
         const bool valid = lane_id() < fa.batchPixels && slot < fp.nPixels;
-        if (valid) init_path(sc, ps, fp, slot);
+        // Frame constants and the shading tables are re-read from the kernel-argument segment where they are used
+        // (the asm makes the pointers opaque, so the loads cannot be hoisted): held across the traversal loop they
+        // cost ~60 scalar registers of a kernel that has none to spare.
+        const FusedKernArgs* kq = opaque_kernarg<FusedKernArgs>();
+        const FrameParams* fq = &kq->fp;
+        const DevScene* sq = &kq->sc;
+        if (valid) init_path(*sq, ps, *fq, slot);
         bool alive = valid && fp.samples > 0;
         unsigned long long mA = __ballot(alive);
         if (alive) list[lanes_below(mA)] = slot << 2;
@@ -1132,7 +1166,9 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(DevScene sc, PathS
             bool nowAlive = false, wantAux = false;
             uint32_t refRays = 0, nPaths = 0;
             if (alive) {
-                shade_path(sc, ps, fp, slot, nowAlive, wantAux, refRays, nPaths);
+                kq = opaque_kernarg<FusedKernArgs>();
+                fq = &kq->fp; sq = &kq->sc;
+                shade_path(*sq, ps, *fq, slot, nowAlive, wantAux, refRays, nPaths);
                 segTot++;
             }
             alive = nowAlive;
@@ -1152,7 +1188,9 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(DevScene sc, PathS
             nRays = nA + 2u * nX;
         }
         __threadfence_block();
-        if (valid) resolve_pixel(ps, fp, fa.rgba, slot);
+        kq = opaque_kernarg<FusedKernArgs>();
+        fq = &kq->fp;
+        if (valid) resolve_pixel(ps, *fq, fa.rgba, slot);
     }
 
     unsigned long long wb = wave_sum_u64(wt.totBox), wtri = wave_sum_u64(wt.totTri);
@@ -1176,14 +1214,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hit_details(DevScene sc, PathState
     if (i >= n) return;
     RtHit h;
     memset(&h, 0, sizeof(h));
-    const float4 hm = ps.hit[RAY_MAIN][i];
+    const float4 hm = ps.hit(RAY_MAIN)[i];
     h.dst = hm.x;
     uint32_t obj = __float_as_uint(hm.y);
     const uint32_t tri = __float_as_uint(hm.z);
     h.boxTests = perRayBox[i];
     h.triTests = perRayTri[i];
     if (obj != RT_HIT_NONE) {
-        FullHit f = reconstruct_hit(sc, f4xyz(ps.rayO[i]), f4xyz(ps.rayD[i]), obj, tri);
+        FullHit f = reconstruct_hit(sc, f4xyz(ps.rayO()[i]), f4xyz(ps.rayD()[i]), obj, tri);
         h.didHit = 1;
         h.isSphere = (obj & RT_HIT_SPHERE) ? 1u : 0u;
         h.objectHitIndex = obj & ~RT_HIT_SPHERE;
@@ -1198,7 +1236,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hit_details(DevScene sc, PathState
 
 __global__ __launch_bounds__(RT_BLOCK) void k_seed_rays(DevScene sc, PathState ps, uint32_t n) {
     uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (i < n) ps.hit[RAY_MAIN][i] = sphere_seed(sc, f4xyz(ps.rayO[i]), f4xyz(ps.rayD[i]));
+    if (i < n) ps.hit(RAY_MAIN)[i] = sphere_seed(sc, f4xyz(ps.rayO()[i]), f4xyz(ps.rayD()[i]));
 }
 
 // ---------------------------------------------------------------- misc kernels
