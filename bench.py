@@ -153,7 +153,8 @@ def main():
         }
         # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes of this same command
         # (tools/pmc_traffic.py -> profiles/); PMC counters cannot be read from inside the process
-        tfile = os.path.join(ROOT, "profiles", f"traffic_k_trace_{args.scene}_{W}x{H}_{args.spp}spp.json")
+        tkern = ["k_trace", "k_render_fused"][r.last_pipeline()]
+        tfile = os.path.join(ROOT, "profiles", f"traffic_{tkern}_{args.scene}_{W}x{H}_{args.spp}spp.json")
         if world == 1 and os.path.exists(tfile):
             with open(tfile) as f:
                 out["roofline"]["traffic"] = json.load(f)["traffic_bytes_per_launch"]

@@ -62,7 +62,7 @@ struct rt_ctx {
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
     int pipeline = -1;      // 0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline (k_render_fused), -1 = by tile size
     int lastPipeline = 0;   // what the last rt_render used
-    uint32_t fusedBelowPixels = 1500000;  // auto: tiles smaller than this use the fused pipeline
+    uint32_t fusedBelowPixels = 4200000;  // auto: tiles smaller than this use the fused pipeline (1080p and 1440p frames do, 4K does not)
     uint32_t fusedBelowBoxTests = 90;     // auto: ... and so do scenes whose rays are short (box tests per ray, measured)
     // box tests per ray of this scene, from counter snapshots copied back asynchronously after each dispatch
     DevCounters* snap = nullptr;          // pinned
@@ -79,6 +79,7 @@ struct rt_ctx {
     int numCUs = 256;
     int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase
     int tileSlots = 1;      // slots follow 8x8 pixel blocks instead of rows
+    int wSetupFused = 16, wLeafFused = 24;  // vote weights of the fused pipeline (short private lists: leaves and set-ups sooner)
     int batchPixels = 0;    // fused pipeline: pixels per wave-private block (0 = chosen per launch)
     int batchFixed = 80;    // ... and the fixed part of a block's cost in the chooser, in pixel units
     int lastBatchPixels = 0;
@@ -234,7 +235,7 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
         overflow = (uint32_t*)c->overflowBuf.p;
     }
     RT_HIP(c, hipMemsetAsync(c->q.counts + 5, 0, 4, c->stream));
-    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, batchPixels};
+    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, (uint32_t)c->wLeafFused, (uint32_t)c->fastLanes, batchPixels};
     c->lastBatchPixels = (int)batchPixels;
     const FusedKernArgs ka{c->sc, c->ps, fp, fa};
     if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
@@ -877,8 +878,10 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "lds_stack") { if (value != 8 && value != 16 && value != 24) return c->fail("lds_stack: 8, 16 or 24"); c->ldsStackCap = value; }
     else if (k == "fast_lanes") { if (value < 1 || value > 65) return c->fail("fast_lanes: 1..65"); c->fastLanes = value; }
     else if (k == "chunk") { if (value < 1 || value > 4096) return c->fail("chunk: 1..4096"); c->chunk = value; }
-    else if (k == "w_setup") { if (value < 1 || value > 512) return c->fail("w_setup: 1..512"); c->wSetup = value; }
-    else if (k == "w_leaf") { if (value < 1 || value > 512) return c->fail("w_leaf: 1..512"); c->wLeaf = value; }
+    else if (k == "w_setup") { if (value < 1 || value > 512) return c->fail("w_setup: 1..512"); c->wSetup = value; c->wSetupFused = value; }
+    else if (k == "w_leaf") { if (value < 1 || value > 512) return c->fail("w_leaf: 1..512"); c->wLeaf = value; c->wLeafFused = value; }
+    else if (k == "mk_w_setup") { if (value < 1 || value > 512) return c->fail("mk_w_setup: 1..512"); c->wSetup = value; }
+    else if (k == "mk_w_leaf") { if (value < 1 || value > 512) return c->fail("mk_w_leaf: 1..512"); c->wLeaf = value; }
     else if (k == "tile_slots") { c->tileSlots = value != 0; }
     else if (k == "batch_pixels") { if (value < 0 || value > (int)RT_WAVE) return c->fail("batch_pixels must be 0 (auto) .. 64"); c->batchPixels = value; }
     else if (k == "batch_fixed") { if (value < 0 || value > 4096) return c->fail("batch_fixed out of range"); c->batchFixed = value; }

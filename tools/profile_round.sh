@@ -13,6 +13,7 @@ grep '^{' $out/bench_under_rocprof.log | tail -1 > $out/bench_under_rocprof.json
 cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- $CMD --cpu-seconds 0 --no-profile > $out/fetch.log 2>&1 || { tail -5 $out/fetch.log; exit 1; }
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- $CMD --cpu-seconds 0 --no-profile > $out/write.log 2>&1 || { tail -5 $out/write.log; exit 1; }
-python tools/pmc_traffic.py $(find $out/fetch -name '*counter_collection.csv' | head -1) $(find $out/write -name '*counter_collection.csv' | head -1) k_trace_pw $out/traffic_k_trace.json "python3 bench.py --steps 3 --warmup 1 --spp 8 (Sponza 1920x1080)"
+kern=$(python3 -c "import json; print('k_render_fused' if 'fused' in json.load(open('$out/bench.json'))['config']['pipeline'] else 'k_trace_pw')")
+python tools/pmc_traffic.py $(find $out/fetch -name '*counter_collection.csv' | head -1) $(find $out/write -name '*counter_collection.csv' | head -1) $kern $out/traffic_$kern.json "python3 bench.py --steps 3 --warmup 1 --spp 8 (Sponza 1920x1080)"
 rm -rf $out/stats $out/fetch $out/write
-cat $out/bench.json | cut -c1-300; head -5 $out/kernel_stats.csv; cat $out/traffic_k_trace.json
+cat $out/bench.json | cut -c1-300; head -5 $out/kernel_stats.csv; cat $out/traffic_$kern.json
