@@ -288,6 +288,9 @@ int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
  *   "trace_variant"  0 = one ray per lane (k_trace), 1 = persistent waves (k_trace_pw)
  *   "refill", "chunk", "w_setup", "w_leaf", "fast_lanes", "lds_stack", "blocks_per_cu",
  *   "tile_slots", "phase_stats": traversal scheduling details, see DESIGN.md
+ *   "scatter"        fused pipeline: a block is made of chunks of this many consecutive slots taken from all
+ *                    over the tile (0 = a block is neighbouring pixels; -1, default = 4 when a wave gets at
+ *                    most two blocks, else 0)
  *   "batch_pixels"   fused pipeline: pixels per wave-private block, 1..64; 0 (default) = chosen per
  *                    launch so the blocks divide evenly over the resident waves ("batch_fixed" is
  *                    the fixed cost per block, in pixel units, that the chooser assumes) */

@@ -1103,6 +1103,7 @@ struct FusedArgs {
     uint32_t* overflow;    // OVF only
     uint32_t refill, wSetup, wLeaf, fastLanes;
     uint32_t batchPixels;  // pixels per wave-private block, <= 64 (chosen by the host so the blocks fill the resident waves evenly)
+    uint32_t scatter;      // g > 0: a block is made of chunks of g consecutive slots taken nBatches chunks apart
 };
 
 // The kernel-argument segment as memory the compiler knows nothing about: loads through the returned pointer
@@ -1139,14 +1140,20 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
     const TracePwArgs ta{nullptr, nullptr, nullptr, fa.refill, 0u, fa.wSetup, fa.wLeaf, fa.fastLanes, nullptr, nullptr, fa.counters, nullptr, nullptr, fa.overflow};
     WaveTotals wt;
     uint32_t refTot = 0, pathTot = 0, segTot = 0;
-    const uint32_t nBatches = (fp.nPixels + fa.batchPixels - 1) / fa.batchPixels;
+    // scatter = g > 0: batchPixels is a multiple of g and a block is batchPixels / g chunks of g slots, nBatches apart
+    const uint32_t nBatches = fa.scatter ? ((fp.nPixels + fa.scatter - 1) / fa.scatter + fa.batchPixels / fa.scatter - 1) / (fa.batchPixels / fa.scatter)
+                                         : (fp.nPixels + fa.batchPixels - 1) / fa.batchPixels;
 
     for (;;) {
         uint32_t batch = 0;
         if (lane_id() == 0) batch = atomicAdd(fa.batchHead, 1u);
         batch = __shfl(batch, 0, RT_WAVE);
         if (batch >= nBatches) break;
-        const uint32_t slot = batch * fa.batchPixels + lane_id();
+        // scatter: a block's pixels are spread over the whole tile (lane * nBatches + batch) instead of being
+        // neighbours, so that all blocks cost about the same when every wave gets just one of them
+        // (chunks of `scatter` consecutive slots, so that the path state is still read in whole 64/128-byte pieces)
+        const uint32_t slot = fa.scatter ? ((lane_id() / fa.scatter) * nBatches + batch) * fa.scatter + (lane_id() % fa.scatter)
+                                         : batch * fa.batchPixels + lane_id();
         const bool valid = lane_id() < fa.batchPixels && slot < fp.nPixels;
         // Frame constants and the shading tables are re-read from the kernel-argument segment where they are used
         // (the asm makes the pointers opaque, so the loads cannot be hoisted): held across the traversal loop they
