@@ -242,7 +242,14 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
         overflow = (uint32_t*)c->overflowBuf.p;
     }
     RT_HIP(c, hipMemsetAsync(c->q.counts + 5, 0, 4, c->stream));
-    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, (uint32_t)c->wLeafFused, (uint32_t)c->fastLanes, batchPixels, g};
+    unsigned long long* waveTimes = nullptr;
+    if (c->phaseStats) {
+        c->waveTimesCount = (size_t)blocks * (RT_BLOCK / RT_WAVE);
+        int rc = dev_alloc(c, c->waveTimeBuf, c->waveTimesCount * 16);
+        if (rc) return rc;
+        waveTimes = (unsigned long long*)c->waveTimeBuf.p;
+    }
+    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, (uint32_t)c->wLeafFused, (uint32_t)c->fastLanes, batchPixels, g, waveTimes};
     c->lastBatchPixels = (int)batchPixels;
     const FusedKernArgs ka{c->sc, c->ps, fp, fa};
     if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);

@@ -1104,6 +1104,7 @@ struct FusedArgs {
     uint32_t refill, wSetup, wLeaf, fastLanes;
     uint32_t batchPixels;  // pixels per wave-private block, <= 64 (chosen by the host so the blocks fill the resident waves evenly)
     uint32_t scatter;      // g > 0: a block is made of chunks of g consecutive slots taken nBatches chunks apart
+    unsigned long long* waveTimes;  // phase_stats only: wall_clock64() at the start and the end of every wave
 };
 
 // The kernel-argument segment as memory the compiler knows nothing about: loads through the returned pointer
@@ -1140,6 +1141,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
     const TracePwArgs ta{nullptr, nullptr, nullptr, fa.refill, 0u, fa.wSetup, fa.wLeaf, fa.fastLanes, nullptr, nullptr, fa.counters, nullptr, nullptr, fa.overflow};
     WaveTotals wt;
     uint32_t refTot = 0, pathTot = 0, segTot = 0;
+    const unsigned long long tKernelStart = fa.waveTimes ? wall_clock64() : 0ull;
     // scatter = g > 0: batchPixels is a multiple of g and a block is batchPixels / g chunks of g slots, nBatches apart
     const uint32_t nBatches = fa.scatter ? ((fp.nPixels + fa.scatter - 1) / fa.scatter + fa.batchPixels / fa.scatter - 1) / (fa.batchPixels / fa.scatter)
                                          : (fp.nPixels + fa.batchPixels - 1) / fa.batchPixels;
@@ -1200,6 +1202,11 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
         if (valid) resolve_pixel(ps, *fq, fa.rgba, slot);
     }
 
+    if (fa.waveTimes && lane_id() == 0) {  // phase_stats: when did this wave run out of blocks?
+        const size_t w = (size_t)blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;
+        fa.waveTimes[2 * w] = tKernelStart;
+        fa.waveTimes[2 * w + 1] = wall_clock64();
+    }
     unsigned long long wb = wave_sum_u64(wt.totBox), wtri = wave_sum_u64(wt.totTri);
     uint32_t wr = wave_sum_u32(wt.totRays), wh = wave_sum_u32(wt.totHits);
     uint32_t wRef = wave_sum_u32(refTot), wP = wave_sum_u32(pathTot), wS = wave_sum_u32(segTot);
