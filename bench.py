@@ -88,13 +88,33 @@ def main():
     fdev = "cpu" if rehearsal else f"cuda:{local}"
     frame = torch.zeros((H, W, 4), dtype=torch.float32, device=fdev) if rank == 0 else None
 
-    def step(i):
+    # N > 1: the strip of step i is copied aside and gathered while step i+1 renders (the progressive blend keeps
+    # its history in `strip`, so the renderer goes on in place); the gather's kernels fill the tail of the render.
+    sendbuf = torch.zeros_like(strip) if world > 1 else None
+    pending = [False]
+
+    def launch(i):
         pc.frameCount = i
-        r.render(pc, W, H, row0=rank, rowStride=world, nRows=len(rows), out_ptr=strip.data_ptr(), sync=True)
+        r.render(pc, W, H, row0=rank, rowStride=world, nRows=len(rows), out_ptr=strip.data_ptr(), sync=False)
+
+    def finish_previous():
+        if pending[0]:
+            tiling.gather_frame(sendbuf.cpu() if rehearsal else sendbuf, frame, H, world, rank)
+            pending[0] = False
+
+    def step(i):
+        launch(i)
         if world > 1:
-            tiling.gather_frame(strip.cpu() if rehearsal else strip, frame, H, world, rank)
+            finish_previous()      # gather of step i-1 overlaps the render of step i
+        r.sync()
+        if world > 1:
+            sendbuf.copy_(strip)
+            torch.cuda.current_stream().synchronize()
+            pending[0] = True
 
     def fence():
+        if world > 1:
+            finish_previous()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
