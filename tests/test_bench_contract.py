@@ -1,0 +1,30 @@
+"""bench.py prints exactly one JSON line with the fields the driver reads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_line_has_the_contract_fields():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--spp", "2",
+                        "--width", "480", "--height", "270", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "Mrays/s" and d["value"] > 0 and d["ms_per_step"] > 0 and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["achieved"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
