@@ -196,6 +196,18 @@ int  rt_scene_find_material(const rt_scene* s, const char* key);
 /* BVH build statistics of the most recent build (printed by the reference, :1187-1193) */
 int  rt_scene_last_bvh_stats(const rt_scene* s, uint32_t* nodeCount, uint32_t* maxDepth, uint32_t* minDepth, uint32_t* maxTri);
 
+/* BVH builder plug. The scene half builds every mesh's BVH on the host, as the reference does
+ * (build_bvh / subdivide / find_split_plane, src/vk_engine.cpp:1169-1337). A hook replaces that step for the meshes added
+ * after it is set: it receives the mesh's triangles and centroids (the last `count` elements of the scene arrays, the
+ * triangles' v0/v1/v2 indexing `points`), must reorder both the way the reference's partition loop does, write the
+ * nodes in the reference's numbering (children of the node at nodeBase + i at nodeBase + nodes[i].index ... as absolute
+ * indices, leaves with absolute triangle indices from triIndex0) and report {maxDepth, minDepth, maxTriCount}.
+ * rt_bvh_hook is such a hook: the same tree, built on the GPU of the rt_ctx passed as `user` (rt_bvh_build). */
+typedef int (*RtBvhBuildHook)(void* user, const TrianglePoint* points, uint32_t pointCount, Triangle* triangles, float* centroids,
+                              uint32_t count, uint32_t triIndex0, uint32_t nodeBase, BVHNode* nodesOut, uint32_t nodeCapacity,
+                              uint32_t* nodeCountOut, uint32_t statsOut[3]);
+int  rt_scene_set_bvh_hook(rt_scene* s, RtBvhBuildHook hook, void* user);
+
 /* Camera/constants half of run_compute (src/vk_engine.cpp:1631-1661):
  * cameraRotation = rotY * rotX * rotZ from Euler degrees. */
 void rt_camera_rotation(const float anglesDeg[3], float outMat4[16]);
@@ -297,6 +309,17 @@ int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
 int  rt_set_tuning(rt_ctx* ctx, const char* key, int value);
 /* pipeline the last rt_render used (0 or 1) */
 int  rt_last_pipeline(const rt_ctx* ctx);
+/* The reference's BVH builder on the GPU (csrc/bvh_build.hip.h): same nodes, same numbering, same triangle order as
+ * the host builder of the scene half (a zero bound may differ in sign). Blocking. `seconds` (optional) = device time. */
+int  rt_bvh_build(rt_ctx* ctx, const TrianglePoint* points, uint32_t pointCount, Triangle* triangles, float* centroids,
+                  uint32_t count, uint32_t triIndex0, uint32_t nodeBase, BVHNode* nodesOut, uint32_t nodeCapacity,
+                  uint32_t* nodeCountOut, uint32_t statsOut[3]);
+int  rt_bvh_hook(void* ctx, const TrianglePoint* points, uint32_t pointCount, Triangle* triangles, float* centroids,
+                 uint32_t count, uint32_t triIndex0, uint32_t nodeBase, BVHNode* nodesOut, uint32_t nodeCapacity,
+                 uint32_t* nodeCountOut, uint32_t statsOut[3]);
+/* milliseconds the last rt_bvh_build spent between its first upload and its last download */
+double rt_bvh_last_build_ms(const rt_ctx* ctx);
+
 /* device self-test of the deterministic-math build (must equal RT_SELFTEST_EXPECT) */
 int  rt_device_selftest(rt_ctx* ctx, uint32_t* bitsOut);
 uint32_t rt_host_selftest(void);

@@ -113,6 +113,7 @@ SYMBOLS = {
     "rt_scene_get_arrays": (C.c_int, [_vp, _P(RtSceneArrays)]),
     "rt_scene_find_material": (C.c_int, [_vp, C.c_char_p]),
     "rt_scene_last_bvh_stats": (C.c_int, [_vp, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
+    "rt_scene_set_bvh_hook": (C.c_int, [_vp, _vp, _vp]),
     "rt_camera_rotation": (None, [_P(C.c_float), _P(C.c_float)]),
     "rt_push_constants_default": (None, [_P(PushConstants), C.c_uint32, C.c_uint32]),
     "rt_transform_matrix": (None, [_P(RtPlacement), _P(C.c_float)]),
@@ -136,6 +137,9 @@ SYMBOLS = {
     "rt_get_trace_time_ms": (C.c_int, [_vp, _P(C.c_double), _P(C.c_uint64)]),
     "rt_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "rt_last_pipeline": (C.c_int, [_vp]),
+    "rt_bvh_build": (C.c_int, [_vp, _P(TrianglePoint), C.c_uint32, _P(Triangle), _P(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, _P(BVHNode), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
+    "rt_bvh_hook": (C.c_int, [_vp, _P(TrianglePoint), C.c_uint32, _P(Triangle), _P(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, _P(BVHNode), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
+    "rt_bvh_last_build_ms": (C.c_double, [_vp]),
     "rt_device_selftest": (C.c_int, [_vp, _P(C.c_uint32)]),
     "rt_host_selftest": (C.c_uint32, []),
     "rt_measure_copy_bandwidth": (C.c_int, [_vp, C.c_size_t, C.c_int, _P(C.c_double)]),

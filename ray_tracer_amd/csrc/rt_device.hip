@@ -7,8 +7,10 @@
 // rt_create fails and nothing else can be called.
 
 #include "rt_kernels.hip.h"
+#include "bvh_build.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -80,6 +82,7 @@ struct rt_ctx {
     int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase
     int tileSlots = 1;      // slots follow 8x8 pixel blocks instead of rows
     int wSetupFused = 16, wLeafFused = 24;  // vote weights of the fused pipeline (short private lists: leaves and set-ups sooner)
+    double bvhBuildMs = 0.0; // last rt_bvh_build
     int scatter = -1;       // fused pipeline: blocks made of chunks of this many slots from all over the tile; 0 = neighbouring pixels; -1 = auto
     int batchPixels = 0;    // fused pipeline: pixels per wave-private block (0 = chosen per launch)
     int batchFixed = 80;    // ... and the fixed part of a block's cost in the chooser, in pixel units
@@ -907,6 +910,105 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
 }
 
 int rt_last_pipeline(const rt_ctx* c) { return c ? c->lastPipeline : -1; }
+
+// ---------------------------------------------------------------- GPU BVH build (bvh_build.hip.h)
+int rt_bvh_build(rt_ctx* c, const TrianglePoint* points, uint32_t pointCount, Triangle* triangles, float* centroids, uint32_t count,
+                 uint32_t triIndex0, uint32_t nodeBase, BVHNode* nodesOut, uint32_t nodeCapacity, uint32_t* nodeCountOut, uint32_t statsOut[3]) {
+    if (!c || !points || !triangles || !centroids || !nodesOut || !nodeCountOut) return -1;
+    if (count == 0) return c->fail("rt_bvh_build: a mesh with 0 triangles");
+    if (nodeCapacity < 2u * count - 1u) return c->fail("rt_bvh_build: node capacity below 2 * count - 1");
+    RT_HIP(c, hipSetDevice(c->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<float> verts((size_t)count * 9);
+    for (uint32_t i = 0; i < count; i++) {
+        const uint32_t vi[3] = {triangles[i].v0, triangles[i].v1, triangles[i].v2};
+        for (int k = 0; k < 3; k++) {
+            if (vi[k] >= pointCount) return c->fail("rt_bvh_build: triangle point index out of range");
+            memcpy(&verts[(size_t)i * 9 + 3 * k], points[vi[k]].position, 12);
+        }
+    }
+    const size_t nNodesMax = 2 * (size_t)count - 1;
+    DevBuf bVerts, bCent, bPerm, bTmp, bHole, bNodes, bList, bCtr;
+    auto release = [&]() { for (DevBuf* b : {&bVerts, &bCent, &bPerm, &bTmp, &bHole, &bNodes, &bList, &bCtr}) dev_free(*b); };
+    int rc;
+    if ((rc = upload(c, bVerts, verts.data(), verts.size() * 4)) || (rc = upload(c, bCent, centroids, (size_t)count * 12)) ||
+        (rc = dev_alloc(c, bPerm, (size_t)count * 4)) || (rc = dev_alloc(c, bTmp, (size_t)count * 4)) || (rc = dev_alloc(c, bHole, (size_t)count * 4)) ||
+        (rc = dev_alloc(c, bNodes, nNodesMax * sizeof(BNode))) || (rc = dev_alloc(c, bList, 2 * (size_t)(count + 1) * 4)) || (rc = dev_alloc(c, bCtr, 64))) {
+        release();
+        return rc;
+    }
+    BvhBuildArgs a{(const float*)bVerts.p, (const float*)bCent.p, (uint32_t*)bPerm.p, (uint32_t*)bTmp.p, (uint32_t*)bHole.p, (BNode*)bNodes.p, (uint32_t*)bCtr.p};
+    uint32_t* lists[2] = {(uint32_t*)bList.p, (uint32_t*)bList.p + (count + 1)};
+    uint32_t* nextCount = (uint32_t*)bCtr.p + 1;
+    hipLaunchKernelGGL(k_bvh_root, dim3(1), dim3(RT_BVH_BLOCK), 0, c->stream, a, count);
+    uint32_t zero = 0, nCur = 1;
+    hipError_t e = hipMemcpyAsync(lists[0], &zero, 4, hipMemcpyHostToDevice, c->stream);  // the root is node 0
+    int cur = 0;
+    for (uint32_t level = 0; e == hipSuccess && nCur && level <= 64; level++) {
+        e = hipMemsetAsync(nextCount, 0, 4, c->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_bvh_level, dim3(nCur), dim3(RT_BVH_BLOCK), 0, c->stream, a, lists[cur], lists[cur ^ 1], nextCount);
+        e = hipMemcpyAsync(&nCur, nextCount, 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        cur ^= 1;
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    uint32_t nNodes = 0;
+    std::vector<BNode> bn;
+    std::vector<uint32_t> perm(count);
+    if (e == hipSuccess) e = hipMemcpy(&nNodes, bCtr.p, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && (nNodes == 0 || nNodes > nNodesMax)) { release(); return c->fail("rt_bvh_build: node counter out of range"); }
+    if (e == hipSuccess) { bn.resize(nNodes); e = hipMemcpy(bn.data(), bNodes.p, (size_t)nNodes * sizeof(BNode), hipMemcpyDeviceToHost); }
+    if (e == hipSuccess) e = hipMemcpy(perm.data(), bPerm.p, (size_t)count * 4, hipMemcpyDeviceToHost);
+    release();
+    if (e != hipSuccess) return c->fail(std::string("rt_bvh_build: ") + hipGetErrorString(e));
+
+    // ---- the reference's numbering: a node's children are allocated when it is split, left subtree first (depth-first)
+    uint32_t nextFree = 1, maxDepth = 0, minDepth = 0xffffffffu, maxTri = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> st;  // (arrival index, output index)
+    st.emplace_back(0u, 0u);
+    while (!st.empty()) {
+        const auto [v, o] = st.back();
+        st.pop_back();
+        const BNode& b = bn[v];
+        BVHNode& out = nodesOut[o];
+        out.boundsX[0] = b.lo[0]; out.boundsX[1] = b.hi[0];
+        out.boundsY[0] = b.lo[1]; out.boundsY[1] = b.hi[1];
+        out.boundsZ[0] = b.lo[2]; out.boundsZ[1] = b.hi[2];
+        if (b.child == 0xffffffffu) {
+            out.index = triIndex0 + b.first;
+            out.triCount = b.count;
+            maxDepth = std::max(maxDepth, b.depth); minDepth = std::min(minDepth, b.depth); maxTri = std::max(maxTri, b.count);
+        } else {
+            if (b.child + 1 >= nNodes || nextFree + 2 > nNodes) return c->fail("rt_bvh_build: inconsistent tree");
+            out.index = nodeBase + nextFree;
+            out.triCount = 0;
+            st.emplace_back(b.child + 1, nextFree + 1);  // right is numbered after the whole left subtree ...
+            st.emplace_back(b.child, nextFree);          // ... but its slot is reserved with the left one
+            nextFree += 2;
+        }
+    }
+    *nodeCountOut = nNodes;
+    if (statsOut) { statsOut[0] = maxDepth; statsOut[1] = minDepth; statsOut[2] = maxTri; }
+
+    // ---- triangles and centroids into the order the partition loops leave them in
+    std::vector<Triangle> tOld(triangles, triangles + count);
+    std::vector<float> cOld(centroids, centroids + (size_t)count * 3);
+    for (uint32_t k2 = 0; k2 < count; k2++) {
+        if (perm[k2] >= count) return c->fail("rt_bvh_build: bad permutation");
+        triangles[k2] = tOld[perm[k2]];
+        memcpy(centroids + 3 * (size_t)k2, &cOld[3 * (size_t)perm[k2]], 12);
+    }
+    c->bvhBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+int rt_bvh_hook(void* ctx, const TrianglePoint* points, uint32_t pointCount, Triangle* triangles, float* centroids, uint32_t count,
+                uint32_t triIndex0, uint32_t nodeBase, BVHNode* nodesOut, uint32_t nodeCapacity, uint32_t* nodeCountOut, uint32_t statsOut[3]) {
+    return rt_bvh_build((rt_ctx*)ctx, points, pointCount, triangles, centroids, count, triIndex0, nodeBase, nodesOut, nodeCapacity, nodeCountOut, statsOut);
+}
+
+double rt_bvh_last_build_ms(const rt_ctx* c) { return c ? c->bvhBuildMs : 0.0; }
 
 int rt_device_selftest(rt_ctx* c, uint32_t* bitsOut) {
     if (!c || !bitsOut) return -1;

@@ -275,8 +275,25 @@ struct rt_scene : public RtSceneHost {
         subdivide(child + 1, depth + 1);
     }
 
+    RtBvhBuildHook bvhHook = nullptr;
+    void* bvhHookUser = nullptr;
+
     int build_bvh(uint32_t size, uint32_t triIndex) {
         if (size == 0) return fail("build_bvh: a mesh group with 0 triangles (undefined in the reference)");
+        if (bvhHook) {  // e.g. the GPU builder (rt_bvh_hook): same nodes, numbering and triangle order
+            const uint32_t offset = (uint32_t)bvhNodes.size();
+            const uint32_t cap = size * 2u - 1u;
+            bvhNodes.resize((size_t)offset + cap, BVHNode{});
+            uint32_t used = 0, st[3] = {0, 0, 0};
+            const int rc = bvhHook(bvhHookUser, triPoints.data(), (uint32_t)triPoints.size(), triangles.data() + triIndex, &centroids[triIndex].v[0],
+                                   size, triIndex, offset, bvhNodes.data() + offset, cap, &used, st);
+            if (rc != 0 || used == 0 || used > cap) { bvhNodes.resize(offset); return fail("build_bvh: the BVH hook failed"); }
+            bvhNodes.resize((size_t)offset + used);
+            bvhNodes.shrink_to_fit();
+            nodesUsed = offset + used;
+            statNodeCount = used; statMaxDepth = st[0]; statMinDepth = st[1]; statMaxTri = st[2];
+            return 0;
+        }
         nodesUsed++;
         uint32_t offset = (uint32_t)bvhNodes.size();
         bvhNodes.resize(bvhNodes.size() + (size_t)size * 2 - 1, BVHNode{});
@@ -698,6 +715,13 @@ int rt_scene_find_material(const rt_scene* s, const char* key) {
     if (!s || !key) return -1;
     auto it = s->loadedMaterials.find(key);
     return it == s->loadedMaterials.end() ? -1 : it->second;
+}
+
+int rt_scene_set_bvh_hook(rt_scene* s, RtBvhBuildHook hook, void* user) {
+    if (!s) return -1;
+    s->bvhHook = hook;
+    s->bvhHookUser = user;
+    return 0;
 }
 
 int rt_scene_last_bvh_stats(const rt_scene* s, uint32_t* nodeCount, uint32_t* maxDepth, uint32_t* minDepth, uint32_t* maxTri) {

@@ -140,6 +140,16 @@ class Scene:
     def prepare_storage_buffers(self, assetDir=ASSET_DIR):
         self._check(self._l.rt_scene_prepare_default(self._h, os.fsencode(assetDir)), "prepare_storage_buffers")
 
+    def use_device_bvh(self, renderer):
+        """Meshes added from now on get their BVH from the GPU builder of `renderer` (rt_bvh_hook):
+        the same nodes, numbering and triangle order as the host builder. None switches back."""
+        if renderer is None:
+            self._check(self._l.rt_scene_set_bvh_hook(self._h, None, None), "rt_scene_set_bvh_hook")
+        else:
+            fn = C.cast(self._l.rt_bvh_hook, C.c_void_p)
+            self._check(self._l.rt_scene_set_bvh_hook(self._h, fn, renderer._h), "rt_scene_set_bvh_hook")
+        self._bvh_renderer = renderer  # keep it alive as long as the hook points at it
+
     def find_material(self, key):
         return self._l.rt_scene_find_material(self._h, key.encode())
 
@@ -310,6 +320,9 @@ class Renderer:
     def last_pipeline(self):
         """0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline."""
         return self._l.rt_last_pipeline(self._h)
+
+    def bvh_last_build_ms(self):
+        return self._l.rt_bvh_last_build_ms(self._h)
 
     def selftest(self):
         b = C.c_uint32()
