@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rt_amd.h"
+
 #define RT_BVH_BINS 20
 #define RT_BVH_BLOCK 256
 
@@ -76,6 +78,7 @@ __device__ __forceinline__ float wave_max_f(float v) {
 }
 
 // exclusive rank of `flag` among the block's threads in thread order, and the block total
+template <int BLOCK>
 __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* s_w, uint32_t& total) {
     const unsigned long long m = __ballot(flag);
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
@@ -85,21 +88,23 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* s_w, uint32_
     __syncthreads();
     uint32_t base = 0;
     total = 0;
-    for (uint32_t i = 0; i < RT_BVH_BLOCK / 64; i++) {
+    for (uint32_t i = 0; i < BLOCK / 64; i++) {
         if (i < w) base += s_w[i];
         total += s_w[i];
     }
     return base + inWave;
 }
 
-__global__ __launch_bounds__(RT_BVH_BLOCK) void k_bvh_level(BvhBuildArgs a, const uint32_t* cur, uint32_t* next, uint32_t* nextCount) {
+// BLOCK: 256 threads per node, 1024 while a level has only a few (big) nodes
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_bvh_level(BvhBuildArgs a, const uint32_t* cur, uint32_t* next, uint32_t* nextCount) {
     __shared__ uint32_t s_cnt[3][RT_BVH_BINS];
     __shared__ uint32_t s_lo[3][RT_BVH_BINS][3], s_hi[3][RT_BVH_BINS][3];
-    __shared__ float s_red[12][RT_BVH_BLOCK / 64];
+    __shared__ float s_red[12][BLOCK / 64];
     __shared__ float s_mn[3], s_mx[3];
     __shared__ float s_split;
     __shared__ int s_axis, s_do;
-    __shared__ uint32_t s_w[RT_BVH_BLOCK / 64];
+    __shared__ uint32_t s_w[BLOCK / 64];
     __shared__ uint32_t s_child;
 
     const uint32_t id = cur[blockIdx.x];
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(RT_BVH_BLOCK) void k_bvh_level(BvhBuildArgs a, cons
     // ---- centroid range per axis (find_split: mn / mx)
     {
         float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
-        for (uint32_t i = tid; i < n; i += RT_BVH_BLOCK) {
+        for (uint32_t i = tid; i < n; i += BLOCK) {
             const float* c = a.cent + 3 * (size_t)a.perm[first + i];
             for (int d = 0; d < 3; d++) { mn[d] = mn[d] < c[d] ? mn[d] : c[d]; mx[d] = mx[d] < c[d] ? c[d] : mx[d]; }
         }
@@ -122,10 +127,10 @@ __global__ __launch_bounds__(RT_BVH_BLOCK) void k_bvh_level(BvhBuildArgs a, cons
         __syncthreads();
         if (tid < 3) {
             float lo = s_red[tid][0], hi = s_red[3 + tid][0];
-            for (uint32_t w = 1; w < RT_BVH_BLOCK / 64; w++) { lo = s_red[tid][w] < lo ? s_red[tid][w] : lo; hi = hi < s_red[3 + tid][w] ? s_red[3 + tid][w] : hi; }
+            for (uint32_t w = 1; w < BLOCK / 64; w++) { lo = s_red[tid][w] < lo ? s_red[tid][w] : lo; hi = hi < s_red[3 + tid][w] ? s_red[3 + tid][w] : hi; }
             s_mn[tid] = lo; s_mx[tid] = hi;
         }
-        for (uint32_t i = tid; i < 3 * RT_BVH_BINS; i += RT_BVH_BLOCK) {
+        for (uint32_t i = tid; i < 3 * RT_BVH_BINS; i += BLOCK) {
             (&s_cnt[0][0])[i] = 0u;
             for (int d = 0; d < 3; d++) { (&s_lo[0][0][0])[3 * i + d] = bvh_key(1e30f); (&s_hi[0][0][0])[3 * i + d] = bvh_key(-1e30f); }
         }
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(RT_BVH_BLOCK) void k_bvh_level(BvhBuildArgs a, cons
     }
 
     // ---- bins of the three axes in one pass (a triangle's three grow_point calls = its own box)
-    for (uint32_t i = tid; i < n; i += RT_BVH_BLOCK) {
+    for (uint32_t i = tid; i < n; i += BLOCK) {
         const uint32_t t = a.perm[first + i];
         const float* v = a.verts + 9 * (size_t)t;
         const float* c = a.cent + 3 * (size_t)t;
@@ -214,20 +219,20 @@ __global__ __launch_bounds__(RT_BVH_BLOCK) void k_bvh_level(BvhBuildArgs a, cons
     uint32_t nL = 0;
     {
         uint32_t cnt = 0;
-        for (uint32_t i = tid; i < n; i += RT_BVH_BLOCK) cnt += isL(i) ? 1u : 0u;
+        for (uint32_t i = tid; i < n; i += BLOCK) cnt += isL(i) ? 1u : 0u;
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
         __syncthreads();
         if (lane == 0) s_w[wv] = cnt;
         __syncthreads();
-        for (uint32_t w = 0; w < RT_BVH_BLOCK / 64; w++) nL += s_w[w];
+        for (uint32_t w = 0; w < BLOCK / 64; w++) nL += s_w[w];
     }
     uint32_t k = 0;  // holes
-    for (uint32_t base = 0; base < nL; base += RT_BVH_BLOCK) {
+    for (uint32_t base = 0; base < nL; base += BLOCK) {
         const uint32_t p = base + tid;
         const bool in = p < nL;
         const bool l = in && isL(p);
         uint32_t tot;
-        const uint32_t r = block_rank(in && !l, s_w, tot);
+        const uint32_t r = block_rank<BLOCK>(in && !l, s_w, tot);
         if (in) {
             if (l) a.tmp[first + p] = a.perm[first + p];
             else a.hole[first + k + r] = p;
@@ -238,13 +243,13 @@ __global__ __launch_bounds__(RT_BVH_BLOCK) void k_bvh_level(BvhBuildArgs a, cons
     {
         uint32_t cBase = 0;  // left elements seen so far, scanning from the right end
         const uint32_t nR = n - nL;
-        for (uint32_t base = 0; base < nR; base += RT_BVH_BLOCK) {
+        for (uint32_t base = 0; base < nR; base += BLOCK) {
             const uint32_t t = base + tid;
             const bool in = t < nR;
             const uint32_t pos = n - 1u - (in ? t : 0u);
             const bool l = in && isL(pos);
             uint32_t tot;
-            const uint32_t c = cBase + block_rank(l, s_w, tot);
+            const uint32_t c = cBase + block_rank<BLOCK>(l, s_w, tot);
             if (in) {
                 if (l) a.tmp[first + a.hole[first + c]] = a.perm[first + pos];
                 uint32_t src;
@@ -257,13 +262,13 @@ __global__ __launch_bounds__(RT_BVH_BLOCK) void k_bvh_level(BvhBuildArgs a, cons
         }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < n; i += RT_BVH_BLOCK) a.perm[first + i] = a.tmp[first + i];
+    for (uint32_t i = tid; i < n; i += BLOCK) a.perm[first + i] = a.tmp[first + i];
     __syncthreads();
     if (nL == 0u || nL == n) return;  // the reference gives up after the partition: leaf with the permuted order
 
     // ---- children: bounds of both ranges in one pass
     float bl[3] = {1e30f, 1e30f, 1e30f}, bh[3] = {-1e30f, -1e30f, -1e30f}, cl[3] = {1e30f, 1e30f, 1e30f}, ch[3] = {-1e30f, -1e30f, -1e30f};
-    for (uint32_t i = tid; i < n; i += RT_BVH_BLOCK) {
+    for (uint32_t i = tid; i < n; i += BLOCK) {
         const float* v = a.verts + 9 * (size_t)a.perm[first + i];
         for (int d = 0; d < 3; d++) {
             float l = v[d], h = v[d];
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(RT_BVH_BLOCK) void k_bvh_level(BvhBuildArgs a, cons
         BNode L, R;
         for (int d = 0; d < 3; d++) {
             float x0 = s_red[d][0], x1 = s_red[3 + d][0], y0 = s_red[6 + d][0], y1 = s_red[9 + d][0];
-            for (uint32_t w = 1; w < RT_BVH_BLOCK / 64; w++) {
+            for (uint32_t w = 1; w < BLOCK / 64; w++) {
                 x0 = s_red[d][w] < x0 ? s_red[d][w] : x0; x1 = x1 < s_red[3 + d][w] ? s_red[3 + d][w] : x1;
                 y0 = s_red[6 + d][w] < y0 ? s_red[6 + d][w] : y0; y1 = y1 < s_red[9 + d][w] ? s_red[9 + d][w] : y1;
             }
@@ -328,4 +333,54 @@ __global__ __launch_bounds__(RT_BVH_BLOCK) void k_bvh_root(BvhBuildArgs a, uint3
         a.nodes[0] = r;
         *a.nodeCounter = 1u;
     }
+}
+
+// ---- the reference's node numbering, on the device. A node's pair of children is allocated when the node is split and the
+// left subtree is finished before the right one is touched, so the pair of an interior node v sits at 1 + 2 * (number of
+// interior nodes before v in left-first pre-order). Levels occupy contiguous ranges of the arrival numbering.
+//   k_bvh_count : bottom-up, interior nodes per subtree
+//   k_bvh_number: top-down, pre-order rank and output slot, and the reference-layout node itself
+struct BvhNumberArgs {
+    const BNode* nodes;
+    uint32_t* inner;   // interior nodes in the subtree
+    uint32_t* rank;    // interior nodes before this one in pre-order (interior nodes only)
+    uint32_t* slot;    // index of the node in the output
+    BVHNode* out;
+    uint32_t* stats;   // [0] max leaf depth [1] min leaf depth [2] max leaf size
+    uint32_t triIndex0, nodeBase;
+};
+
+__global__ __launch_bounds__(256) void k_bvh_count(BvhNumberArgs a, uint32_t begin, uint32_t end) {
+    const uint32_t v = begin + blockIdx.x * 256u + threadIdx.x;
+    if (v >= end) return;
+    const uint32_t c = a.nodes[v].child;
+    a.inner[v] = c == 0xffffffffu ? 0u : 1u + a.inner[c] + a.inner[c + 1u];
+}
+
+__global__ __launch_bounds__(256) void k_bvh_number(BvhNumberArgs a, uint32_t begin, uint32_t end) {
+    const uint32_t v = begin + blockIdx.x * 256u + threadIdx.x;
+    if (v >= end) return;
+    const BNode b = a.nodes[v];
+    const uint32_t o = v == 0u ? 0u : a.slot[v];
+    BVHNode n;
+    n.boundsX[0] = b.lo[0]; n.boundsX[1] = b.hi[0];
+    n.boundsY[0] = b.lo[1]; n.boundsY[1] = b.hi[1];
+    n.boundsZ[0] = b.lo[2]; n.boundsZ[1] = b.hi[2];
+    if (b.child == 0xffffffffu) {
+        n.index = a.triIndex0 + b.first;
+        n.triCount = b.count;
+        atomicMax(&a.stats[0], b.depth);
+        atomicMin(&a.stats[1], b.depth);
+        atomicMax(&a.stats[2], b.count);
+    } else {
+        const uint32_t r = v == 0u ? 0u : a.rank[v];
+        const uint32_t pair = 1u + 2u * r;
+        n.index = a.nodeBase + pair;
+        n.triCount = 0u;
+        a.slot[b.child] = pair;
+        a.slot[b.child + 1u] = pair + 1u;
+        a.rank[b.child] = r + 1u;
+        a.rank[b.child + 1u] = r + 1u + a.inner[b.child];
+    }
+    a.out[o] = n;
 }

@@ -919,6 +919,8 @@ int rt_bvh_build(rt_ctx* c, const TrianglePoint* points, uint32_t pointCount, Tr
     if (nodeCapacity < 2u * count - 1u) return c->fail("rt_bvh_build: node capacity below 2 * count - 1");
     RT_HIP(c, hipSetDevice(c->device));
     const auto t0 = std::chrono::steady_clock::now();
+    const bool dbg = getenv("RT_BVH_DEBUG") != nullptr;
+    auto mark = [&](const char* what) { if (dbg) fprintf(stderr, "[rt_bvh_build] %-12s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
     std::vector<float> verts((size_t)count * 9);
     for (uint32_t i = 0; i < count; i++) {
         const uint32_t vi[3] = {triangles[i].v0, triangles[i].v1, triangles[i].v2};
@@ -937,6 +939,7 @@ int rt_bvh_build(rt_ctx* c, const TrianglePoint* points, uint32_t pointCount, Tr
         release();
         return rc;
     }
+    mark("uploaded");
     BvhBuildArgs a{(const float*)bVerts.p, (const float*)bCent.p, (uint32_t*)bPerm.p, (uint32_t*)bTmp.p, (uint32_t*)bHole.p, (BNode*)bNodes.p, (uint32_t*)bCtr.p};
     uint32_t* lists[2] = {(uint32_t*)bList.p, (uint32_t*)bList.p + (count + 1)};
     uint32_t* nextCount = (uint32_t*)bCtr.p + 1;
@@ -944,52 +947,59 @@ int rt_bvh_build(rt_ctx* c, const TrianglePoint* points, uint32_t pointCount, Tr
     uint32_t zero = 0, nCur = 1;
     hipError_t e = hipMemcpyAsync(lists[0], &zero, 4, hipMemcpyHostToDevice, c->stream);  // the root is node 0
     int cur = 0;
+    std::vector<uint32_t> levelStart{0u, 1u};  // arrival numbers of the nodes of level l: [levelStart[l], levelStart[l + 1])
     for (uint32_t level = 0; e == hipSuccess && nCur && level <= 64; level++) {
         e = hipMemsetAsync(nextCount, 0, 4, c->stream);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(k_bvh_level, dim3(nCur), dim3(RT_BVH_BLOCK), 0, c->stream, a, lists[cur], lists[cur ^ 1], nextCount);
+        // threads per node by the size of the level's nodes: the whole mesh is spread over nCur of them
+        if (nCur <= 32) hipLaunchKernelGGL(k_bvh_level<1024>, dim3(nCur), dim3(1024), 0, c->stream, a, lists[cur], lists[cur ^ 1], nextCount);
+        else if (count / nCur >= 128) hipLaunchKernelGGL(k_bvh_level<256>, dim3(nCur), dim3(256), 0, c->stream, a, lists[cur], lists[cur ^ 1], nextCount);
+        else hipLaunchKernelGGL(k_bvh_level<64>, dim3(nCur), dim3(64), 0, c->stream, a, lists[cur], lists[cur ^ 1], nextCount);
         e = hipMemcpyAsync(&nCur, nextCount, 4, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (nCur) levelStart.push_back(levelStart.back() + nCur);
         cur ^= 1;
     }
     if (e == hipSuccess) e = hipGetLastError();
+    mark("levels done");
     uint32_t nNodes = 0;
-    std::vector<BNode> bn;
-    std::vector<uint32_t> perm(count);
     if (e == hipSuccess) e = hipMemcpy(&nNodes, bCtr.p, 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && (nNodes == 0 || nNodes > nNodesMax)) { release(); return c->fail("rt_bvh_build: node counter out of range"); }
-    if (e == hipSuccess) { bn.resize(nNodes); e = hipMemcpy(bn.data(), bNodes.p, (size_t)nNodes * sizeof(BNode), hipMemcpyDeviceToHost); }
-    if (e == hipSuccess) e = hipMemcpy(perm.data(), bPerm.p, (size_t)count * 4, hipMemcpyDeviceToHost);
-    release();
-    if (e != hipSuccess) return c->fail(std::string("rt_bvh_build: ") + hipGetErrorString(e));
+    if (e == hipSuccess && (nNodes == 0 || nNodes > nNodesMax || nNodes != levelStart.back())) { release(); return c->fail("rt_bvh_build: node counter out of range"); }
 
-    // ---- the reference's numbering: a node's children are allocated when it is split, left subtree first (depth-first)
-    uint32_t nextFree = 1, maxDepth = 0, minDepth = 0xffffffffu, maxTri = 0;
-    std::vector<std::pair<uint32_t, uint32_t>> st;  // (arrival index, output index)
-    st.emplace_back(0u, 0u);
-    while (!st.empty()) {
-        const auto [v, o] = st.back();
-        st.pop_back();
-        const BNode& b = bn[v];
-        BVHNode& out = nodesOut[o];
-        out.boundsX[0] = b.lo[0]; out.boundsX[1] = b.hi[0];
-        out.boundsY[0] = b.lo[1]; out.boundsY[1] = b.hi[1];
-        out.boundsZ[0] = b.lo[2]; out.boundsZ[1] = b.hi[2];
-        if (b.child == 0xffffffffu) {
-            out.index = triIndex0 + b.first;
-            out.triCount = b.count;
-            maxDepth = std::max(maxDepth, b.depth); minDepth = std::min(minDepth, b.depth); maxTri = std::max(maxTri, b.count);
-        } else {
-            if (b.child + 1 >= nNodes || nextFree + 2 > nNodes) return c->fail("rt_bvh_build: inconsistent tree");
-            out.index = nodeBase + nextFree;
-            out.triCount = 0;
-            st.emplace_back(b.child + 1, nextFree + 1);  // right is numbered after the whole left subtree ...
-            st.emplace_back(b.child, nextFree);          // ... but its slot is reserved with the left one
-            nextFree += 2;
-        }
+    // ---- the reference's numbering (bvh_build.hip.h): interior counts bottom-up, slots top-down, nodes written in place
+    DevBuf bNum, bOut;
+    uint32_t hstats[3] = {0u, 0xffffffffu, 0u};
+    if (e == hipSuccess && ((rc = dev_alloc(c, bNum, 3 * (size_t)nNodes * 4 + 64)) || (rc = dev_alloc(c, bOut, (size_t)nNodes * sizeof(BVHNode))))) {
+        release(); dev_free(bNum); dev_free(bOut);
+        return rc;
     }
+    std::vector<uint32_t> perm(count);
+    if (e == hipSuccess) {
+        uint32_t* nb = (uint32_t*)bNum.p;
+        uint32_t* dstats = nb + 3 * (size_t)nNodes;
+        BvhNumberArgs na{(const BNode*)bNodes.p, nb, nb + nNodes, nb + 2 * (size_t)nNodes, (BVHNode*)bOut.p, dstats, triIndex0, nodeBase};
+        e = hipMemcpyAsync(dstats, hstats, 12, hipMemcpyHostToDevice, c->stream);
+        const int nLevels = (int)levelStart.size() - 1;
+        for (int l = nLevels - 1; l >= 0 && e == hipSuccess; l--) {
+            const uint32_t b0 = levelStart[l], b1 = levelStart[l + 1];
+            hipLaunchKernelGGL(k_bvh_count, dim3((b1 - b0 + 255) / 256), dim3(256), 0, c->stream, na, b0, b1);
+        }
+        for (int l = 0; l < nLevels && e == hipSuccess; l++) {
+            const uint32_t b0 = levelStart[l], b1 = levelStart[l + 1];
+            hipLaunchKernelGGL(k_bvh_number, dim3((b1 - b0 + 255) / 256), dim3(256), 0, c->stream, na, b0, b1);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(nodesOut, bOut.p, (size_t)nNodes * sizeof(BVHNode), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hstats, dstats, 12, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(perm.data(), bPerm.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    mark("numbered");
+    release();
+    dev_free(bNum); dev_free(bOut);
+    if (e != hipSuccess) return c->fail(std::string("rt_bvh_build: ") + hipGetErrorString(e));
     *nodeCountOut = nNodes;
-    if (statsOut) { statsOut[0] = maxDepth; statsOut[1] = minDepth; statsOut[2] = maxTri; }
+    if (statsOut) { statsOut[0] = hstats[0]; statsOut[1] = hstats[1]; statsOut[2] = hstats[2]; }
 
     // ---- triangles and centroids into the order the partition loops leave them in
     std::vector<Triangle> tOld(triangles, triangles + count);
@@ -999,6 +1009,7 @@ int rt_bvh_build(rt_ctx* c, const TrianglePoint* points, uint32_t pointCount, Tr
         triangles[k2] = tOld[perm[k2]];
         memcpy(centroids + 3 * (size_t)k2, &cOld[3 * (size_t)perm[k2]], 12);
     }
+    mark("permuted");
     c->bvhBuildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
 }

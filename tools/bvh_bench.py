@@ -1,0 +1,21 @@
+"""Host builder vs GPU builder of the reference's BVH (same output, tests/test_bvh_device.py): wall time per mesh."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ray_tracer_amd import engine, scenes  # noqa: E402
+
+r = engine.Renderer(0)
+for ntris, seed in ((69451, 2), (262267, 1), (871414, 3)):
+    pos, nrm = scenes.blob(ntris, seed=seed)
+    for rep in range(2):
+        host = engine.Scene()
+        t = time.perf_counter(); host.add_mesh("m", pos, nrm, engine.placement(), 0); th = time.perf_counter() - t
+        dev = engine.Scene(); dev.use_device_bvh(r)
+        t = time.perf_counter(); dev.add_mesh("m", pos, nrm, engine.placement(), 0); td = time.perf_counter() - t
+    st = dev.last_bvh_stats()
+    print(f"{ntris:7d} triangles: add_mesh with the host builder {th * 1e3:8.1f} ms, with the device builder {td * 1e3:8.1f} ms "
+          f"(rt_bvh_build {r.bvh_last_build_ms():7.1f} ms); {st['nodeCount']} nodes, depth {st['minDepth']}..{st['maxDepth']}", flush=True)
