@@ -116,6 +116,7 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_level(BvhBuildArgs a, const uint3
     // ---- centroid range per axis (find_split: mn / mx)
     {
         float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+#pragma unroll 4
         for (uint32_t i = tid; i < n; i += BLOCK) {
             const float* c = a.cent + 3 * (size_t)a.perm[first + i];
             for (int d = 0; d < 3; d++) { mn[d] = mn[d] < c[d] ? mn[d] : c[d]; mx[d] = mx[d] < c[d] ? c[d] : mx[d]; }
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_level(BvhBuildArgs a, const uint3
     }
 
     // ---- bins of the three axes in one pass (a triangle's three grow_point calls = its own box)
+#pragma unroll 4
     for (uint32_t i = tid; i < n; i += BLOCK) {
         const uint32_t t = a.perm[first + i];
         const float* v = a.verts + 9 * (size_t)t;
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_level(BvhBuildArgs a, const uint3
     uint32_t nL = 0;
     {
         uint32_t cnt = 0;
+#pragma unroll 4
         for (uint32_t i = tid; i < n; i += BLOCK) cnt += isL(i) ? 1u : 0u;
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
         __syncthreads();
@@ -262,12 +265,14 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_level(BvhBuildArgs a, const uint3
         }
     }
     __syncthreads();
+#pragma unroll 4
     for (uint32_t i = tid; i < n; i += BLOCK) a.perm[first + i] = a.tmp[first + i];
     __syncthreads();
     if (nL == 0u || nL == n) return;  // the reference gives up after the partition: leaf with the permuted order
 
     // ---- children: bounds of both ranges in one pass
     float bl[3] = {1e30f, 1e30f, 1e30f}, bh[3] = {-1e30f, -1e30f, -1e30f}, cl[3] = {1e30f, 1e30f, 1e30f}, ch[3] = {-1e30f, -1e30f, -1e30f};
+#pragma unroll 4
     for (uint32_t i = tid; i < n; i += BLOCK) {
         const float* v = a.verts + 9 * (size_t)a.perm[first + i];
         for (int d = 0; d < 3; d++) {
