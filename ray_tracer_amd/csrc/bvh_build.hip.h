@@ -95,7 +95,50 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* s_w, uint32_
     return base + inWave;
 }
 
-// BLOCK: 256 threads per node, 1024 while a level has only a few (big) nodes
+// The 19-candidate sweep of find_split_plane over the three axes, one thread, in the host's order. cnt/lo/hi are
+// [3][RT_BVH_BINS] and [3][RT_BVH_BINS][3] (keys). Returns whether the node is split.
+__device__ bool bvh_sweep(const float* mnA, const float* mxA, const uint32_t* cnt, const uint32_t* lo, const uint32_t* hi, const BNode& nd,
+                          int& axis, float& splitPos) {
+    const unsigned B = RT_BVH_BINS;
+    float best = 1e30f;
+    axis = 0;
+    splitPos = 0.f;
+    for (int ax = 0; ax < 3; ax++) {
+        const float mn = mnA[ax], mx = mxA[ax];
+        if (mn == mx) continue;
+        float leftArea[RT_BVH_BINS - 1], rightArea[RT_BVH_BINS - 1];
+        float leftCount[RT_BVH_BINS - 1], rightCount[RT_BVH_BINS - 1];
+        BBox leftBox, rightBox;
+        int leftSum = 0, rightSum = 0;
+        for (unsigned i = 0; i < B - 1; i++) {
+            BBox bl, br;
+            for (int d = 0; d < 3; d++) {
+                bl.lo[d] = bvh_unkey(lo[(ax * B + i) * 3 + d]); bl.hi[d] = bvh_unkey(hi[(ax * B + i) * 3 + d]);
+                br.lo[d] = bvh_unkey(lo[(ax * B + (B - 1 - i)) * 3 + d]); br.hi[d] = bvh_unkey(hi[(ax * B + (B - 1 - i)) * 3 + d]);
+            }
+            leftSum += (int)cnt[ax * B + i];
+            leftCount[i] = (float)leftSum;
+            leftBox.grow_box(bl);
+            leftArea[i] = leftBox.surface_area();
+            rightSum += (int)cnt[ax * B + (B - 1 - i)];
+            rightCount[B - 2 - i] = (float)rightSum;
+            rightBox.grow_box(br);
+            rightArea[i] = rightBox.surface_area();          // the reference's double store (src/vk_engine.cpp:1321-1322)
+            rightArea[B - 2 - i] = rightBox.surface_area();
+        }
+        const float scale = (mx - mn) / (float)B;
+        for (unsigned i = 0; i < B - 1; i++) {
+            const float cost = leftCount[i] * leftArea[i] + rightCount[i] * rightArea[i];
+            if (cost < best) { axis = ax; splitPos = mn + scale * (float)(i + 1); best = cost; }
+        }
+    }
+    BBox parent;
+    for (int d = 0; d < 3; d++) { parent.lo[d] = nd.lo[d]; parent.hi[d] = nd.hi[d]; }
+    const float noSplit = (float)nd.count * parent.surface_area();
+    return !(best >= noSplit);
+}
+
+// BLOCK: 256 threads per node (64 for the small nodes of deep levels)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_bvh_level(BvhBuildArgs a, const uint32_t* cur, uint32_t* next, uint32_t* nextCount) {
     __shared__ uint32_t s_cnt[3][RT_BVH_BINS];
@@ -166,42 +209,9 @@ __global__ __launch_bounds__(BLOCK) void k_bvh_level(BvhBuildArgs a, const uint3
 
     // ---- the sweep, sequentially, as the host does it
     if (tid == 0) {
-        const unsigned B = RT_BVH_BINS;
-        float best = 1e30f, splitPos = 0.f;
         int axis = 0;
-        for (int ax = 0; ax < 3; ax++) {
-            const float mn = s_mn[ax], mx = s_mx[ax];
-            if (mn == mx) continue;
-            float leftArea[RT_BVH_BINS - 1], rightArea[RT_BVH_BINS - 1];
-            float leftCount[RT_BVH_BINS - 1], rightCount[RT_BVH_BINS - 1];
-            BBox leftBox, rightBox;
-            int leftSum = 0, rightSum = 0;
-            for (unsigned i = 0; i < B - 1; i++) {
-                BBox bl, br;
-                for (int d = 0; d < 3; d++) {
-                    bl.lo[d] = bvh_unkey(s_lo[ax][i][d]); bl.hi[d] = bvh_unkey(s_hi[ax][i][d]);
-                    br.lo[d] = bvh_unkey(s_lo[ax][B - 1 - i][d]); br.hi[d] = bvh_unkey(s_hi[ax][B - 1 - i][d]);
-                }
-                leftSum += (int)s_cnt[ax][i];
-                leftCount[i] = (float)leftSum;
-                leftBox.grow_box(bl);
-                leftArea[i] = leftBox.surface_area();
-                rightSum += (int)s_cnt[ax][B - 1 - i];
-                rightCount[B - 2 - i] = (float)rightSum;
-                rightBox.grow_box(br);
-                rightArea[i] = rightBox.surface_area();          // the reference's double store (src/vk_engine.cpp:1321-1322)
-                rightArea[B - 2 - i] = rightBox.surface_area();
-            }
-            const float scale = (mx - mn) / (float)B;
-            for (unsigned i = 0; i < B - 1; i++) {
-                const float cost = leftCount[i] * leftArea[i] + rightCount[i] * rightArea[i];
-                if (cost < best) { axis = ax; splitPos = mn + scale * (float)(i + 1); best = cost; }
-            }
-        }
-        BBox parent;
-        for (int d = 0; d < 3; d++) { parent.lo[d] = nd.lo[d]; parent.hi[d] = nd.hi[d]; }
-        const float noSplit = (float)n * parent.surface_area();
-        s_do = best >= noSplit ? 0 : 1;
+        float splitPos = 0.f;
+        s_do = bvh_sweep(s_mn, s_mx, &s_cnt[0][0], &s_lo[0][0][0], &s_hi[0][0][0], nd, axis, splitPos) ? 1 : 0;
         s_axis = axis;
         s_split = splitPos;
     }
@@ -338,6 +348,250 @@ __global__ __launch_bounds__(RT_BVH_BLOCK) void k_bvh_root(BvhBuildArgs a, uint3
         a.nodes[0] = r;
         *a.nodeCounter = 1u;
     }
+}
+
+// ---------------------------------------------------------------- wide path: the first levels, many work-groups per node
+// While a level has only a few nodes, each holding a large share of the mesh, one work-group per node leaves the GPU empty
+// (the root level of an 871 k-triangle mesh took 17 of the builder's 50 ms). The same steps, split into kernels over chunks
+// of RT_BVH_CHUNK positions (grid: chunks x nodes of the level), with the node's accumulators in global memory:
+//   w_init -> w_minmax -> w_bins -> w_sweep -> w_count -> w_scan -> w_left -> w_right -> w_commit -> w_finish
+// The partition's closed form only needs PL(p) = number of left elements before position p: per-chunk counts, one scan over
+// the chunks, and a scan inside each chunk.
+#define RT_BVH_CHUNK 2048u
+#define RT_BVH_WIDE_NODES 32u   // levels with at most this many nodes take the wide path
+struct WideAcc {
+    uint32_t mn[3], mx[3];                                  // keys
+    uint32_t cnt[3 * RT_BVH_BINS], lo[3 * RT_BVH_BINS * 3], hi[3 * RT_BVH_BINS * 3];
+    uint32_t clo[3], chi[3], dlo[3], dhi[3];                // bounds of the left / right child, keys
+    float split;
+    int axis, doSplit;
+    uint32_t nL, k;
+};
+struct WideArgs {
+    BvhBuildArgs b;
+    const uint32_t* cur;
+    WideAcc* acc;        // one per node of the level
+    uint32_t* chunkL;    // [nodes][maxChunks]: left elements per chunk, then their exclusive scan
+    uint32_t maxChunks;
+    uint32_t* next;
+    uint32_t* nextCount;
+};
+
+__global__ __launch_bounds__(64) void w_init(WideArgs w) {
+    WideAcc& A = w.acc[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < 3; i += 64) { A.mn[i] = bvh_key(1e30f); A.mx[i] = bvh_key(-1e30f); A.clo[i] = A.dlo[i] = bvh_key(1e30f); A.chi[i] = A.dhi[i] = bvh_key(-1e30f); }
+    for (uint32_t i = threadIdx.x; i < 3 * RT_BVH_BINS; i += 64) A.cnt[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < 3 * RT_BVH_BINS * 3; i += 64) { A.lo[i] = bvh_key(1e30f); A.hi[i] = bvh_key(-1e30f); }
+    if (threadIdx.x == 0) { A.split = 0.f; A.axis = 0; A.doSplit = 0; A.nL = 0u; A.k = 0u; }
+}
+
+__global__ __launch_bounds__(256) void w_minmax(WideArgs w) {
+    const BNode nd = w.b.nodes[w.cur[blockIdx.y]];
+    const uint32_t n = nd.count, first = nd.first, base = blockIdx.x * RT_BVH_CHUNK;
+    if (n <= 2u || nd.depth >= 64u || base >= n) return;
+    const uint32_t end = min(n, base + RT_BVH_CHUNK);
+    float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+    for (uint32_t i = base + threadIdx.x; i < end; i += 256) {
+        const float* c = w.b.cent + 3 * (size_t)w.b.perm[first + i];
+        for (int d = 0; d < 3; d++) { mn[d] = mn[d] < c[d] ? mn[d] : c[d]; mx[d] = mx[d] < c[d] ? c[d] : mx[d]; }
+    }
+    WideAcc& A = w.acc[blockIdx.y];
+    for (int d = 0; d < 3; d++) {
+        const float lo = wave_min_f(mn[d]), hi = wave_max_f(mx[d]);
+        if ((threadIdx.x & 63u) == 0) { atomicMin(&A.mn[d], bvh_key(lo)); atomicMax(&A.mx[d], bvh_key(hi)); }
+    }
+}
+
+__global__ __launch_bounds__(256) void w_bins(WideArgs w) {
+    __shared__ uint32_t s_cnt[3 * RT_BVH_BINS], s_lo[3 * RT_BVH_BINS * 3], s_hi[3 * RT_BVH_BINS * 3];
+    const BNode nd = w.b.nodes[w.cur[blockIdx.y]];
+    const uint32_t n = nd.count, first = nd.first, base = blockIdx.x * RT_BVH_CHUNK;
+    if (n <= 2u || nd.depth >= 64u || base >= n) return;
+    const uint32_t end = min(n, base + RT_BVH_CHUNK);
+    WideAcc& A = w.acc[blockIdx.y];
+    for (uint32_t i = threadIdx.x; i < 3 * RT_BVH_BINS; i += 256) s_cnt[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < 3 * RT_BVH_BINS * 3; i += 256) { s_lo[i] = bvh_key(1e30f); s_hi[i] = bvh_key(-1e30f); }
+    __syncthreads();
+    float mnA[3], mxA[3];
+    for (int d = 0; d < 3; d++) { mnA[d] = bvh_unkey(A.mn[d]); mxA[d] = bvh_unkey(A.mx[d]); }
+    for (uint32_t i = base + threadIdx.x; i < end; i += 256) {
+        const uint32_t t = w.b.perm[first + i];
+        const float* v = w.b.verts + 9 * (size_t)t;
+        const float* c = w.b.cent + 3 * (size_t)t;
+        float tl[3], th[3];
+        for (int d = 0; d < 3; d++) {
+            float l = v[d], h = v[d];
+            l = v[3 + d] < l ? v[3 + d] : l; h = h < v[3 + d] ? v[3 + d] : h;
+            l = v[6 + d] < l ? v[6 + d] : l; h = h < v[6 + d] ? v[6 + d] : h;
+            tl[d] = l; th[d] = h;
+        }
+        for (int ax = 0; ax < 3; ax++) {
+            const float mn = mnA[ax], mx = mxA[ax];
+            if (mn == mx) continue;
+            const float scale = (float)RT_BVH_BINS / (mx - mn);
+            const float f = floorf((c[ax] - mn) * scale);
+            const float lim = (float)(RT_BVH_BINS - 1);
+            const int bi = (int)(lim < f ? lim : f);
+            atomicAdd(&s_cnt[ax * RT_BVH_BINS + bi], 1u);
+            for (int d = 0; d < 3; d++) { atomicMin(&s_lo[(ax * RT_BVH_BINS + bi) * 3 + d], bvh_key(tl[d])); atomicMax(&s_hi[(ax * RT_BVH_BINS + bi) * 3 + d], bvh_key(th[d])); }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 3 * RT_BVH_BINS; i += 256) {
+        if (s_cnt[i]) {
+            atomicAdd(&A.cnt[i], s_cnt[i]);
+            for (int d = 0; d < 3; d++) { atomicMin(&A.lo[3 * i + d], s_lo[3 * i + d]); atomicMax(&A.hi[3 * i + d], s_hi[3 * i + d]); }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void w_sweep(WideArgs w) {
+    if (threadIdx.x) return;
+    const BNode nd = w.b.nodes[w.cur[blockIdx.x]];
+    if (nd.count <= 2u || nd.depth >= 64u) return;
+    WideAcc& A = w.acc[blockIdx.x];
+    float mnA[3], mxA[3];
+    for (int d = 0; d < 3; d++) { mnA[d] = bvh_unkey(A.mn[d]); mxA[d] = bvh_unkey(A.mx[d]); }
+    int axis;
+    float split;
+    A.doSplit = bvh_sweep(mnA, mxA, A.cnt, A.lo, A.hi, nd, axis, split) ? 1 : 0;
+    A.axis = axis;
+    A.split = split;
+}
+
+// left elements per chunk
+__global__ __launch_bounds__(256) void w_count(WideArgs w) {
+    __shared__ uint32_t s_w[4];
+    const WideAcc& A = w.acc[blockIdx.y];
+    const BNode nd = w.b.nodes[w.cur[blockIdx.y]];
+    const uint32_t n = nd.count, first = nd.first, base = blockIdx.x * RT_BVH_CHUNK;
+    if (!A.doSplit || base >= n) return;
+    const uint32_t end = min(n, base + RT_BVH_CHUNK);
+    uint32_t cnt = 0;
+    for (uint32_t i = base + threadIdx.x; i < end; i += 256) cnt += (w.b.cent[3 * (size_t)w.b.perm[first + i] + A.axis] < A.split) ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) w.chunkL[blockIdx.y * w.maxChunks + blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// exclusive scan of the chunk counts of one node (one work-group, sequential over at most a few hundred chunks per thread 0)
+__global__ __launch_bounds__(64) void w_scan(WideArgs w) {
+    if (threadIdx.x) return;
+    WideAcc& A = w.acc[blockIdx.x];
+    const BNode nd = w.b.nodes[w.cur[blockIdx.x]];
+    if (!A.doSplit) return;
+    const uint32_t chunks = (nd.count + RT_BVH_CHUNK - 1) / RT_BVH_CHUNK;
+    uint32_t run = 0;
+    uint32_t* c = w.chunkL + blockIdx.x * w.maxChunks;
+    for (uint32_t i = 0; i < chunks; i++) { const uint32_t v = c[i]; c[i] = run; run += v; }
+    A.nL = run;
+}
+
+// PL(p) for the positions of a chunk: lane order inside the work-group follows positions; returns via arrays in registers
+//   left part: left elements stay, right elements register as holes (hole rank = p - PL(p))
+__global__ __launch_bounds__(256) void w_left(WideArgs w) {
+    __shared__ uint32_t s_w[4];
+    WideAcc& A = w.acc[blockIdx.y];
+    const BNode nd = w.b.nodes[w.cur[blockIdx.y]];
+    const uint32_t n = nd.count, first = nd.first, base = blockIdx.x * RT_BVH_CHUNK;
+    if (!A.doSplit || base >= n) return;
+    const uint32_t nL = A.nL;
+    uint32_t run = w.chunkL[blockIdx.y * w.maxChunks + blockIdx.x];  // PL(base)
+    for (uint32_t off = 0; off < RT_BVH_CHUNK; off += 256) {
+        const uint32_t p = base + off + threadIdx.x;
+        const bool in = p < n;
+        const bool l = in && (w.b.cent[3 * (size_t)w.b.perm[first + p] + A.axis] < A.split);
+        uint32_t tot;
+        const uint32_t pl = run + block_rank<256>(l, s_w, tot);  // PL(p)
+        if (in && p < nL) {
+            if (l) w.b.tmp[first + p] = w.b.perm[first + p];
+            else w.b.hole[first + (p - pl)] = p;
+        }
+        if (in && nL > 0u && p == nL - 1u) A.k = nL - (pl + (l ? 1u : 0u));  // holes = right elements in [0, nL)
+        run += tot;
+        if (base + off + 256 >= n) break;
+    }
+}
+
+//   right part (after every hole is known)
+__global__ __launch_bounds__(256) void w_right(WideArgs w) {
+    __shared__ uint32_t s_w[4];
+    const WideAcc& A = w.acc[blockIdx.y];
+    const BNode nd = w.b.nodes[w.cur[blockIdx.y]];
+    const uint32_t n = nd.count, first = nd.first, base = blockIdx.x * RT_BVH_CHUNK;
+    if (!A.doSplit || base >= n) return;
+    const uint32_t nL = A.nL, k = A.k;
+    uint32_t run = w.chunkL[blockIdx.y * w.maxChunks + blockIdx.x];
+    for (uint32_t off = 0; off < RT_BVH_CHUNK; off += 256) {
+        const uint32_t pos = base + off + threadIdx.x;
+        const bool in = pos < n;
+        const bool l = in && (w.b.cent[3 * (size_t)w.b.perm[first + pos] + A.axis] < A.split);
+        uint32_t tot;
+        const uint32_t pl = run + block_rank<256>(l, s_w, tot);
+        if (in && pos >= nL) {
+            const uint32_t c = nL - (pl + (l ? 1u : 0u));  // left elements in (pos, n-1]
+            if (l) w.b.tmp[first + w.b.hole[first + c]] = w.b.perm[first + pos];
+            uint32_t src;
+            if (pos == n - 1u) src = k ? w.b.hole[first] : nL;
+            else if (!(w.b.cent[3 * (size_t)w.b.perm[first + pos + 1u] + A.axis] < A.split)) src = pos + 1u;
+            else src = c < k ? w.b.hole[first + c] : nL;
+            w.b.tmp[first + pos] = w.b.perm[first + src];
+        }
+        run += tot;
+        if (base + off + 256 >= n) break;
+    }
+}
+
+//   the new order becomes the order; bounds of the two children
+__global__ __launch_bounds__(256) void w_commit(WideArgs w) {
+    WideAcc& A = w.acc[blockIdx.y];
+    const BNode nd = w.b.nodes[w.cur[blockIdx.y]];
+    const uint32_t n = nd.count, first = nd.first, base = blockIdx.x * RT_BVH_CHUNK;
+    if (!A.doSplit || base >= n) return;
+    const uint32_t end = min(n, base + RT_BVH_CHUNK), nL = A.nL;
+    float bl[3] = {1e30f, 1e30f, 1e30f}, bh[3] = {-1e30f, -1e30f, -1e30f}, cl[3] = {1e30f, 1e30f, 1e30f}, ch[3] = {-1e30f, -1e30f, -1e30f};
+    for (uint32_t i = base + threadIdx.x; i < end; i += 256) {
+        const uint32_t t = w.b.tmp[first + i];
+        w.b.perm[first + i] = t;
+        const float* v = w.b.verts + 9 * (size_t)t;
+        for (int d = 0; d < 3; d++) {
+            float l = v[d], h = v[d];
+            l = v[3 + d] < l ? v[3 + d] : l; h = h < v[3 + d] ? v[3 + d] : h;
+            l = v[6 + d] < l ? v[6 + d] : l; h = h < v[6 + d] ? v[6 + d] : h;
+            if (i < nL) { bl[d] = l < bl[d] ? l : bl[d]; bh[d] = bh[d] < h ? h : bh[d]; }
+            else { cl[d] = l < cl[d] ? l : cl[d]; ch[d] = ch[d] < h ? h : ch[d]; }
+        }
+    }
+    for (int d = 0; d < 3; d++) {
+        const float x0 = wave_min_f(bl[d]), x1 = wave_max_f(bh[d]), y0 = wave_min_f(cl[d]), y1 = wave_max_f(ch[d]);
+        if ((threadIdx.x & 63u) == 0) {
+            atomicMin(&A.clo[d], bvh_key(x0)); atomicMax(&A.chi[d], bvh_key(x1));
+            atomicMin(&A.dlo[d], bvh_key(y0)); atomicMax(&A.dhi[d], bvh_key(y1));
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void w_finish(WideArgs w) {
+    if (threadIdx.x) return;
+    const WideAcc& A = w.acc[blockIdx.x];
+    const uint32_t id = w.cur[blockIdx.x];
+    const BNode nd = w.b.nodes[id];
+    if (!A.doSplit || A.nL == 0u || A.nL == nd.count) return;  // leaf (the second case keeps the permuted order, as the reference does)
+    const uint32_t child = atomicAdd(w.b.nodeCounter, 2u);
+    BNode L, R;
+    for (int d = 0; d < 3; d++) {
+        L.lo[d] = bvh_unkey(A.clo[d]); L.hi[d] = bvh_unkey(A.chi[d]);
+        R.lo[d] = bvh_unkey(A.dlo[d]); R.hi[d] = bvh_unkey(A.dhi[d]);
+    }
+    L.first = nd.first; L.count = A.nL; L.child = 0xffffffffu; L.depth = nd.depth + 1u;
+    R.first = nd.first + A.nL; R.count = nd.count - A.nL; R.child = 0xffffffffu; R.depth = nd.depth + 1u;
+    w.b.nodes[child] = L;
+    w.b.nodes[child + 1u] = R;
+    w.b.nodes[id].child = child;
+    const uint32_t at = atomicAdd(w.nextCount, 2u);
+    w.next[at] = child;
+    w.next[at + 1u] = child + 1u;
 }
 
 // ---- the reference's node numbering, on the device. A node's pair of children is allocated when the node is split and the

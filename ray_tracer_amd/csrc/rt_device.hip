@@ -930,12 +930,14 @@ int rt_bvh_build(rt_ctx* c, const TrianglePoint* points, uint32_t pointCount, Tr
         }
     }
     const size_t nNodesMax = 2 * (size_t)count - 1;
-    DevBuf bVerts, bCent, bPerm, bTmp, bHole, bNodes, bList, bCtr;
-    auto release = [&]() { for (DevBuf* b : {&bVerts, &bCent, &bPerm, &bTmp, &bHole, &bNodes, &bList, &bCtr}) dev_free(*b); };
+    DevBuf bVerts, bCent, bPerm, bTmp, bHole, bNodes, bList, bCtr, bWide;
+    auto release = [&]() { for (DevBuf* b : {&bVerts, &bCent, &bPerm, &bTmp, &bHole, &bNodes, &bList, &bCtr, &bWide}) dev_free(*b); };
+    const uint32_t maxChunks = (count + RT_BVH_CHUNK - 1) / RT_BVH_CHUNK;
     int rc;
     if ((rc = upload(c, bVerts, verts.data(), verts.size() * 4)) || (rc = upload(c, bCent, centroids, (size_t)count * 12)) ||
         (rc = dev_alloc(c, bPerm, (size_t)count * 4)) || (rc = dev_alloc(c, bTmp, (size_t)count * 4)) || (rc = dev_alloc(c, bHole, (size_t)count * 4)) ||
-        (rc = dev_alloc(c, bNodes, nNodesMax * sizeof(BNode))) || (rc = dev_alloc(c, bList, 2 * (size_t)(count + 1) * 4)) || (rc = dev_alloc(c, bCtr, 64))) {
+        (rc = dev_alloc(c, bNodes, nNodesMax * sizeof(BNode))) || (rc = dev_alloc(c, bList, 2 * (size_t)(count + 1) * 4)) || (rc = dev_alloc(c, bCtr, 64)) ||
+        (rc = dev_alloc(c, bWide, RT_BVH_WIDE_NODES * sizeof(WideAcc) + (size_t)RT_BVH_WIDE_NODES * maxChunks * 4))) {
         release();
         return rc;
     }
@@ -952,7 +954,21 @@ int rt_bvh_build(rt_ctx* c, const TrianglePoint* points, uint32_t pointCount, Tr
         e = hipMemsetAsync(nextCount, 0, 4, c->stream);
         if (e != hipSuccess) break;
         // threads per node by the size of the level's nodes: the whole mesh is spread over nCur of them
-        if (nCur <= 32) hipLaunchKernelGGL(k_bvh_level<1024>, dim3(nCur), dim3(1024), 0, c->stream, a, lists[cur], lists[cur ^ 1], nextCount);
+        if (nCur <= RT_BVH_WIDE_NODES && count >= 8192u) {  // big nodes: many work-groups per node (bvh_build.hip.h, wide path)
+            const WideArgs w{a, lists[cur], (WideAcc*)bWide.p, (uint32_t*)((char*)bWide.p + RT_BVH_WIDE_NODES * sizeof(WideAcc)), maxChunks, lists[cur ^ 1], nextCount};
+            const dim3 gc(maxChunks, nCur), gn(nCur);
+            hipLaunchKernelGGL(w_init, gn, dim3(64), 0, c->stream, w);
+            hipLaunchKernelGGL(w_minmax, gc, dim3(256), 0, c->stream, w);
+            hipLaunchKernelGGL(w_bins, gc, dim3(256), 0, c->stream, w);
+            hipLaunchKernelGGL(w_sweep, gn, dim3(64), 0, c->stream, w);
+            hipLaunchKernelGGL(w_count, gc, dim3(256), 0, c->stream, w);
+            hipLaunchKernelGGL(w_scan, gn, dim3(64), 0, c->stream, w);
+            hipLaunchKernelGGL(w_left, gc, dim3(256), 0, c->stream, w);
+            hipLaunchKernelGGL(w_right, gc, dim3(256), 0, c->stream, w);
+            hipLaunchKernelGGL(w_commit, gc, dim3(256), 0, c->stream, w);
+            hipLaunchKernelGGL(w_finish, gn, dim3(64), 0, c->stream, w);
+        }
+        else if (nCur <= 32) hipLaunchKernelGGL(k_bvh_level<1024>, dim3(nCur), dim3(1024), 0, c->stream, a, lists[cur], lists[cur ^ 1], nextCount);
         else if (count / nCur >= 128) hipLaunchKernelGGL(k_bvh_level<256>, dim3(nCur), dim3(256), 0, c->stream, a, lists[cur], lists[cur ^ 1], nextCount);
         else hipLaunchKernelGGL(k_bvh_level<64>, dim3(nCur), dim3(64), 0, c->stream, a, lists[cur], lists[cur ^ 1], nextCount);
         e = hipMemcpyAsync(&nCur, nextCount, 4, hipMemcpyDeviceToHost, c->stream);
