@@ -21,6 +21,7 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--phase-stats", action="store_true")
 ap.add_argument("--bounce", type=int, default=8)
 ap.add_argument("--ntris", type=int, default=0, help="sponza stand-in triangle count (0 = default)")
+ap.add_argument("--row-stride", type=int, default=1, help="render only rows 0, s, 2s, ... (what rank 0 of s GPUs renders)")
 ap.add_argument("--variants", default="v0;v1,refill=8;v1,refill=16;v1,refill=24;v1,refill=32;v1,refill=48")
 args = ap.parse_args()
 
@@ -50,7 +51,7 @@ for rnd in range(args.rounds + 1):
         r.reset_counters()
         r.set_profiling(True)
         t = time.perf_counter()
-        img = r.render(pc, W, H)
+        img = r.render(pc, W, H, row0=0, rowStride=args.row_stride)
         dt = (time.perf_counter() - t) * 1e3
         tms, nl = r.trace_time_ms()
         r.set_profiling(False)
