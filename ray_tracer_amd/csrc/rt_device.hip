@@ -81,6 +81,7 @@ struct rt_ctx {
     int numCUs = 256;
     int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase
     int tileSlots = 1;      // slots follow 8x8 pixel blocks instead of rows
+    bool fastLanesSet = false;  // fast_lanes given explicitly: it then also applies to the fused pipeline
     int wSetupFused = 16, wLeafFused = 24;  // vote weights of the fused pipeline (short private lists: leaves and set-ups sooner)
     double bvhBuildMs = 0.0; // last rt_bvh_build
     int scatter = -1;       // fused pipeline: blocks made of chunks of this many slots from all over the tile; 0 = neighbouring pixels; -1 = auto
@@ -245,6 +246,9 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
         overflow = (uint32_t*)c->overflowBuf.p;
     }
     RT_HIP(c, hipMemsetAsync(c->q.counts + 5, 0, 4, c->stream));
+    // lanes at interior nodes that make the wave skip the vote: long rays (Sponza: 157 box tests per ray) want the interior step
+    // to wait for more lanes (40: -4 %), short rays (Cornell + model: 33..37) for fewer (16: -1 %); 24 until the scene is measured
+    const uint32_t fastLanes = c->fastLanesSet ? (uint32_t)c->fastLanes : (c->boxPerRay < 0.0 ? 24u : (c->boxPerRay >= (double)c->fusedBelowBoxTests ? 40u : 16u));
     unsigned long long* waveTimes = nullptr;
     if (c->phaseStats) {
         c->waveTimesCount = (size_t)blocks * (RT_BLOCK / RT_WAVE);
@@ -252,7 +256,7 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
         if (rc) return rc;
         waveTimes = (unsigned long long*)c->waveTimeBuf.p;
     }
-    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, (uint32_t)c->wLeafFused, (uint32_t)c->fastLanes, batchPixels, g, waveTimes};
+    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, (uint32_t)c->wLeafFused, fastLanes, batchPixels, g, waveTimes};
     c->lastBatchPixels = (int)batchPixels;
     const FusedKernArgs ka{c->sc, c->ps, fp, fa};
     if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
@@ -893,7 +897,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
     else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; }
     else if (k == "lds_stack") { if (value != 8 && value != 16 && value != 24) return c->fail("lds_stack: 8, 16 or 24"); c->ldsStackCap = value; }
-    else if (k == "fast_lanes") { if (value < 1 || value > 65) return c->fail("fast_lanes: 1..65"); c->fastLanes = value; }
+    else if (k == "fast_lanes") { if (value < 0 || value > 65) return c->fail("fast_lanes: 1..65 (0: back to the defaults)"); c->fastLanesSet = value != 0; c->fastLanes = value ? value : 24; }
     else if (k == "chunk") { if (value < 1 || value > 4096) return c->fail("chunk: 1..4096"); c->chunk = value; }
     else if (k == "w_setup") { if (value < 1 || value > 512) return c->fail("w_setup: 1..512"); c->wSetup = value; c->wSetupFused = value; }
     else if (k == "w_leaf") { if (value < 1 || value > 512) return c->fail("w_leaf: 1..512"); c->wLeaf = value; c->wLeafFused = value; }
