@@ -76,7 +76,7 @@ struct rt_ctx {
     int chunk = 256;        // k_trace_pw: most queue entries reserved per atomic
     int ldsStackCap = 24;   // k_trace_pw: LDS stack entries per lane (8, 16 or 24); deeper BVHs use the overflow buffer
     int fastLanes = 32;     // k_trace_pw: lanes at interior nodes that skip the full vote (4K Sponza: 24 -> 32 is -2 %, 1080p: equal)
-    int wSetup = 32, wLeaf = 8; // k_trace_pw: vote weights in eighths (interior = 8)
+    int wSetup = 16, wLeaf = 16; // k_trace_pw: vote weights in eighths (interior = 8); 4K Sponza: -5 % against 32 / 8
     int blocksPerCU = 0;    // k_trace_pw: 0 = occupancy query
     int numCUs = 256;
     int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase
