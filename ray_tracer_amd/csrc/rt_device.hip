@@ -64,7 +64,7 @@ struct rt_ctx {
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
     int pipeline = -1;      // 0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline (k_render_fused), -1 = by tile size
     int lastPipeline = 0;   // what the last rt_render used
-    uint32_t fusedBelowPixels = 4200000;  // auto: tiles smaller than this use the fused pipeline (1080p and 1440p frames do, 4K does not)
+    uint32_t fusedBelowPixels = 2800000;  // auto: tiles smaller than this use the fused pipeline (a 1080p frame does, 1440p and 4K do not)
     uint32_t fusedBelowBoxTests = 90;     // auto: ... and so do scenes whose rays are short (box tests per ray, measured)
     // box tests per ray of this scene, from counter snapshots copied back asynchronously after each dispatch
     DevCounters* snap = nullptr;          // pinned
