@@ -81,6 +81,7 @@ struct rt_ctx {
     int numCUs = 256;
     int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase
     int tileSlots = 1;      // slots follow 8x8 pixel blocks instead of rows
+    bool wLeafSet = false;
     bool fastLanesSet = false;  // fast_lanes given explicitly: it then also applies to the fused pipeline
     int wSetupFused = 16, wLeafFused = 24;  // vote weights of the fused pipeline (short private lists: leaves and set-ups sooner)
     double bvhBuildMs = 0.0; // last rt_bvh_build
@@ -249,6 +250,8 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
     // lanes at interior nodes that make the wave skip the vote: long rays (Sponza: 157 box tests per ray) want the interior step
     // to wait for more lanes (40: -4 %), short rays (Cornell + model: 33..37) for fewer (16: -1 %); 24 until the scene is measured
     const uint32_t fastLanes = c->fastLanesSet ? (uint32_t)c->fastLanes : (c->boxPerRay < 0.0 ? 24u : (c->boxPerRay >= (double)c->fusedBelowBoxTests ? 40u : 16u));
+    const bool shortRays = c->boxPerRay >= 0.0 && c->boxPerRay < (double)c->fusedBelowBoxTests;
+    const uint32_t wLeaf = (!c->wLeafSet && shortRays) ? 16u : (uint32_t)c->wLeafFused;  // short rays: 16 is 1-2 % better than 24
     unsigned long long* waveTimes = nullptr;
     if (c->phaseStats) {
         c->waveTimesCount = (size_t)blocks * (RT_BLOCK / RT_WAVE);
@@ -256,7 +259,7 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
         if (rc) return rc;
         waveTimes = (unsigned long long*)c->waveTimeBuf.p;
     }
-    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, (uint32_t)c->wLeafFused, fastLanes, batchPixels, g, waveTimes};
+    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, wLeaf, fastLanes, batchPixels, g, waveTimes};
     c->lastBatchPixels = (int)batchPixels;
     const FusedKernArgs ka{c->sc, c->ps, fp, fa};
     if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
@@ -900,7 +903,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "fast_lanes") { if (value < 0 || value > 65) return c->fail("fast_lanes: 1..65 (0: back to the defaults)"); c->fastLanesSet = value != 0; c->fastLanes = value ? value : 32; }
     else if (k == "chunk") { if (value < 1 || value > 4096) return c->fail("chunk: 1..4096"); c->chunk = value; }
     else if (k == "w_setup") { if (value < 1 || value > 512) return c->fail("w_setup: 1..512"); c->wSetup = value; c->wSetupFused = value; }
-    else if (k == "w_leaf") { if (value < 1 || value > 512) return c->fail("w_leaf: 1..512"); c->wLeaf = value; c->wLeafFused = value; }
+    else if (k == "w_leaf") { if (value < 1 || value > 512) return c->fail("w_leaf: 1..512"); c->wLeaf = value; c->wLeafFused = value; c->wLeafSet = true; }
     else if (k == "mk_w_setup") { if (value < 1 || value > 512) return c->fail("mk_w_setup: 1..512"); c->wSetup = value; }
     else if (k == "mk_w_leaf") { if (value < 1 || value > 512) return c->fail("mk_w_leaf: 1..512"); c->wLeaf = value; }
     else if (k == "tile_slots") { c->tileSlots = value != 0; }
