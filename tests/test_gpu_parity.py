@@ -319,3 +319,31 @@ def test_long_sample_chains_on_sampled_rows(renderer):
     pc = scenes.sponza_camera(W, H, singleRender=1, sampleLimit=64)
     tile = dict(row0=67, rowStride=135, nRows=8)
     _check(*_render_both(renderer, s, pc, W, H, **tile))
+
+
+def test_automatic_pipeline_choice(renderer):
+    """pipeline -1: small tiles go to the fused kernel, big tiles of long-ray scenes to the multi-kernel pipeline, and a
+    scene whose measured rays are short goes to the fused kernel at any size (the ray cost comes back asynchronously:
+    it is known at the latest two synchronised dispatches after the first)."""
+    r = renderer
+    r.set_tuning("pipeline", -1)
+    scene = cornell_scene()
+    r.upload_scene(scene)
+    pc = engine.push_constants(256, 256, singleRender=1, sampleLimit=1)
+    r.render(pc, 256, 256)
+    assert r.last_pipeline() == 1
+    W, H = 2560, 1440  # 3.7 M pixels
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=1)
+    for _ in range(3):
+        r.render(pc, W, H)
+    assert r.last_pipeline() == 1, "Cornell has ~10 box tests per ray"
+    sp, _ = scenes.sponza(0, ntris=20000)
+    r.upload_scene(sp)
+    pc = scenes.sponza_camera(W, H, singleRender=1, sampleLimit=1)
+    r.render(pc, W, H)
+    assert r.last_pipeline() == 0, "not measured yet: by size"
+    for _ in range(2):
+        r.render(pc, W, H)
+    assert r.last_pipeline() == 0, "long rays (26 objects): the multi-kernel pipeline keeps big tiles"
+    r.render(scenes.sponza_camera(1920, 1080, singleRender=1, sampleLimit=1), 1920, 1080)
+    assert r.last_pipeline() == 1
