@@ -347,3 +347,59 @@ def test_automatic_pipeline_choice(renderer):
     assert r.last_pipeline() == 0, "long rays (26 objects): the multi-kernel pipeline keeps big tiles"
     r.render(scenes.sponza_camera(1920, 1080, singleRender=1, sampleLimit=1), 1920, 1080)
     assert r.last_pipeline() == 1
+
+
+def test_instances_nonuniform_transforms_emissive_mesh_and_ten_spheres(renderer):
+    """One OBJ loaded four times (cached BVH, src/vk_engine.cpp:802-815) under rotated, non-uniformly scaled and mirrored
+    placements, one instance emissive (a second light the hard-wired NEE knows nothing about), one dielectric; all ten
+    sphere slots in use with every material kind, some overlapping; environment on."""
+    import os
+    s = engine.Scene()
+    s.prepare_storage_buffers()
+    bunny = os.path.join(engine.ASSET_DIR, "bunny.obj")
+    glow = s.add_material(engine.default_material(albedo=(0.9, 0.6, 0.2), emissionColor=(1.0, 0.5, 0.1), emissionStrength=3.0))
+    s.read_obj(bunny, engine.placement(position=(-0.45, 0.55, 0.2), scale=(0.5, 0.9, 0.5), rotation=(0, 40, 0)), 0)
+    s.read_obj(bunny, engine.placement(position=(0.45, 0.55, 0.1), scale=(0.6, 0.4, 0.8), rotation=(15, -70, 10)), 5)
+    s.read_obj(bunny, engine.placement(position=(0.0, -0.6, 0.5), scale=(-0.5, 0.5, 0.5), rotation=(180, 0, 0)), glow)
+    s.read_obj(bunny, engine.placement(position=(0.0, 0.6, -0.5), scale=(0.3, 0.3, 0.3), rotation=(0, 0, 90)), 4)
+    kinds = [0, 1, 2, 4, 5, glow, 5, 4, 0, 3]
+    for i in range(10):
+        a = i * 0.7
+        s.set_sphere(i, (0.7 * np.cos(a), -0.1 + 0.08 * i - 0.4, 0.6 * np.sin(a)), 0.12 + 0.02 * (i % 4), kinds[i])
+    W, H = 112, 80
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3, bounceLimit=6, environmentOn=True)
+    _check(*_render_both(renderer, s, pc, W, H))
+
+
+def test_camera_inside_a_mesh_and_grazing_rays(renderer):
+    """The camera sits inside the klein bottle (back faces first, frontFace = false paths of the dielectric) and looks along
+    a wall (grazing primary rays); a wide field of view sends rays past every edge of the box."""
+    s = model_scene("klein_bottle.obj", material=5, scale=0.9, position=(0.0, 0.2, 0.0))
+    W, H = 96, 72
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2, bounceLimit=10, pos=(0.02, 0.15, 0.03),
+                               cameraAngles=(3.0, 88.0, 0.0), fov=120.0)
+    _check(*_render_both(renderer, s, pc, W, H))
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2, pos=(-0.995, -0.3, -0.9), cameraAngles=(0.0, 0.5, 0.0), fov=60.0)
+    _check(*_render_both(renderer, s, pc, W, H))
+
+
+def test_degenerate_and_coincident_triangles(renderer):
+    """Zero-area triangles, zero-length normals (normalize(0) = NaN in the reference, H8), two coincident quads of
+    different materials (equal hit distances: the strict '<' keeps the first one met), a triangle through the camera."""
+    s = engine.Scene()
+    s.prepare_storage_buffers()
+    quad = np.array([[[-0.5, 0.2, 0.3], [0.5, 0.2, 0.3], [0.5, -0.6, 0.3]], [[-0.5, 0.2, 0.3], [0.5, -0.6, 0.3], [-0.5, -0.6, 0.3]]], np.float32)
+    nq = np.zeros_like(quad); nq[..., 2] = -1
+    s.add_mesh("quad_a", quad, nq, engine.placement(), 1)
+    s.add_mesh("quad_b", quad.copy(), nq, engine.placement(), 2)            # same place, other material
+    deg = np.array([[[0.1, 0.1, 0.0], [0.1, 0.1, 0.0], [0.1, 0.1, 0.0]],     # a point
+                    [[-0.3, 0.0, -0.2], [0.3, 0.0, -0.2], [0.0, 0.0, -0.2]],  # a segment
+                    [[-0.2, -0.3, -0.4], [0.2, -0.3, -0.4], [0.0, -0.1, -0.4]]], np.float32)
+    nd = np.zeros_like(deg)                                                  # zero normals on a real triangle too
+    s.add_mesh("degenerate", deg, nd, engine.placement(), 0)
+    thru = np.array([[[0.0, -0.5, -3.6], [0.3, -0.2, -2.0], [-0.3, -0.2, -2.0]]], np.float32)  # passes next to the eye
+    nt = np.zeros_like(thru); nt[..., 1] = -1
+    s.add_mesh("through", thru, nt, engine.placement(), 4)
+    W, H = 96, 72
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3)
+    _check(*_render_both(renderer, s, pc, W, H))
