@@ -300,6 +300,8 @@ int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
  *   "trace_variant"  0 = one ray per lane (k_trace), 1 = persistent waves (k_trace_pw)
  *   "refill", "chunk", "w_setup", "w_leaf", "fast_lanes", "lds_stack", "blocks_per_cu",
  *   "tile_slots", "phase_stats": traversal scheduling details, see DESIGN.md
+ *   "fast_share"     sixteenths of the lanes that hold a ray which suffice to skip the vote (with "fast_lanes" as the
+ *                    upper limit; 0 = "fast_lanes" only)
  *   "scatter"        fused pipeline: a block is made of chunks of this many consecutive slots taken from all
  *                    over the tile (0 = a block is neighbouring pixels; -1, default = 4 when a wave gets at
  *                    most two blocks, else 0)

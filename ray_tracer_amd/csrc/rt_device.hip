@@ -85,6 +85,7 @@ struct rt_ctx {
     bool fastLanesSet = false;  // fast_lanes given explicitly: it then also applies to the fused pipeline
     int wSetupFused = 16, wLeafFused = 24;  // vote weights of the fused pipeline (short private lists: leaves and set-ups sooner)
     double bvhBuildMs = 0.0; // last rt_bvh_build
+    int fastShare = 10;     // sixteenths of the live lanes that suffice to skip the vote (0 = fixed count only): -1..-2 % everywhere
     int scatter = -1;       // fused pipeline: blocks made of chunks of this many slots from all over the tile; 0 = neighbouring pixels; -1 = auto
     int batchPixels = 0;    // fused pipeline: pixels per wave-private block (0 = chosen per launch)
     int batchFixed = 80;    // ... and the fixed part of a block's cost in the chooser, in pixel units
@@ -193,7 +194,7 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
         if (rc) return rc;
         waveTimes = (unsigned long long*)c->waveTimeBuf.p;
     }
-    TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refill, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes,
+    TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refill, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, (uint32_t)c->fastShare,
                    ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), waveTimes, overflow};
     // per-ray counters are only needed for the pixel heat maps (debug >= 0) and rt_trace_rays
     const bool pix = c->pixStats || ta.perRayBox;
@@ -259,7 +260,7 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
         if (rc) return rc;
         waveTimes = (unsigned long long*)c->waveTimeBuf.p;
     }
-    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, wLeaf, fastLanes, batchPixels, g, waveTimes};
+    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, wLeaf, fastLanes, batchPixels, g, (uint32_t)c->fastShare, waveTimes};
     c->lastBatchPixels = (int)batchPixels;
     const FusedKernArgs ka{c->sc, c->ps, fp, fa};
     if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
@@ -907,6 +908,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "mk_w_setup") { if (value < 1 || value > 512) return c->fail("mk_w_setup: 1..512"); c->wSetup = value; }
     else if (k == "mk_w_leaf") { if (value < 1 || value > 512) return c->fail("mk_w_leaf: 1..512"); c->wLeaf = value; }
     else if (k == "tile_slots") { c->tileSlots = value != 0; }
+    else if (k == "fast_share") { if (value < 0 || value > 16) return c->fail("fast_share: 0..16"); c->fastShare = value; }
     else if (k == "scatter") { if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return c->fail("scatter: -1 (auto), 0, 1, 2, 4, 8 or 16"); c->scatter = value; }
     else if (k == "batch_pixels") { if (value < 0 || value > (int)RT_WAVE) return c->fail("batch_pixels must be 0 (auto) .. 64"); c->batchPixels = value; }
     else if (k == "batch_fixed") { if (value < 0 || value > 4096) return c->fail("batch_fixed out of range"); c->batchFixed = value; }

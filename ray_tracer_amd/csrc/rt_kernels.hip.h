@@ -405,6 +405,7 @@ struct TracePwArgs {
     uint32_t chunk;           // most queue entries a wave reserves per atomic (guided: fewer near the end)
     uint32_t wSetup, wLeaf;   // vote weights in eighths (interior = 8)
     uint32_t fastLanes;       // go straight to the interior step when at least this many lanes are at interior nodes
+    uint32_t fastShare;       // ... but at most this many sixteenths of the lanes that hold a ray (0 = off)
     uint32_t* perRayBox;      // PIX only
     uint32_t* perRayTri;
     DevCounters* counters;
@@ -452,6 +453,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
     uint32_t resBase = 0, resCount = LOCAL ? n : 0u;  // reserved queue entries not yet dealt out
     uint32_t nextChunk = LOCAL ? 0u : min(ta.chunk, max(16u, n / (2u * gridDim.x * (RT_BLOCK / RT_WAVE))));
 
+    uint32_t thr = ta.fastLanes;
+
     auto fetch_next_meta = [&]() {
         if (obj < sc.objectCount) {
             const uint4 m = sc.objMeta[obj];
@@ -464,7 +467,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
         int roundKind = 2;
         const unsigned long long mI = __ballot((int32_t)cur >= 0);
         uint32_t nI = __popcll(mI);
-        bool runI = nI >= ta.fastLanes;
+        bool runI = nI >= thr;
         if (!runI) {
             // ================= slow path: refill, full vote, leaf and setup steps =================
             // refill: hand queue entries to idle lanes (the ray itself is loaded by the setup step). The wave
@@ -473,6 +476,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
             const unsigned long long mIdle = __ballot(cur == RT_CUR_IDLE);
             const uint32_t nIdle = __popcll(mIdle);
             if (nIdle == RT_WAVE && exhausted && resCount == 0) break;
+            // the share of the live lanes that skips the vote, not a fixed count: while a list drains the wave keeps its fast path
+            if (ta.fastShare) thr = min(ta.fastLanes, max(4u, ((RT_WAVE - nIdle) * ta.fastShare) >> 4));
             if (nIdle >= ta.refill && (resCount || !exhausted)) {
                 if (resCount == 0) {
                     uint32_t base = 0;
@@ -1104,6 +1109,7 @@ struct FusedArgs {
     uint32_t refill, wSetup, wLeaf, fastLanes;
     uint32_t batchPixels;  // pixels per wave-private block, <= 64 (chosen by the host so the blocks fill the resident waves evenly)
     uint32_t scatter;      // g > 0: a block is made of chunks of g consecutive slots taken nBatches chunks apart
+    uint32_t fastShare;
     unsigned long long* waveTimes;  // phase_stats only: wall_clock64() at the start and the end of every wave
 };
 
@@ -1138,7 +1144,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
     uint32_t* list = s_list[wv];
     uint32_t* ovf = OVF ? fa.overflow + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x : nullptr;
     const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
-    const TracePwArgs ta{nullptr, nullptr, nullptr, fa.refill, 0u, fa.wSetup, fa.wLeaf, fa.fastLanes, nullptr, nullptr, fa.counters, nullptr, nullptr, fa.overflow};
+    const TracePwArgs ta{nullptr, nullptr, nullptr, fa.refill, 0u, fa.wSetup, fa.wLeaf, fa.fastLanes, fa.fastShare, nullptr, nullptr, fa.counters, nullptr, nullptr, fa.overflow};
     WaveTotals wt;
     uint32_t refTot = 0, pathTot = 0, segTot = 0;
     const unsigned long long tKernelStart = fa.waveTimes ? wall_clock64() : 0ull;
