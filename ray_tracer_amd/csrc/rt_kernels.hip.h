@@ -517,7 +517,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
             }
 
             if (runL) {
-                // ---------------- leaf step: one triangle (all of them for a leaf with > 7)
+                // ---------------- leaf step: up to two triangles (all of them for a leaf with > 7)
                 if ((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX) {
                     const uint32_t cnt = (cur >> RT_LEAF_CNT_SHIFT) & 7u;
                     uint32_t j = cur & RT_LEAF_IDX_MASK, jEnd;
@@ -527,8 +527,9 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         jEnd += j;
                         cur = RT_CUR_NEED;
                     } else {
-                        jEnd = j + 1;
-                        cur = (cnt > 1u) ? (cur + 1u - (1u << RT_LEAF_CNT_SHIFT)) : RT_CUR_NEED;
+                        const uint32_t take = min(cnt, 2u);  // two triangles per step: their loads overlap; 1, 3 and 'all' measured slower
+                        jEnd = j + take;
+                        cur = (cnt > take) ? (cur + take - (take << RT_LEAF_CNT_SHIFT)) : RT_CUR_NEED;
                     }
                     if (PIX) rayTri += jEnd - j; else wt.totTri += jEnd - j;
                     for (; j < jEnd; j++) {
