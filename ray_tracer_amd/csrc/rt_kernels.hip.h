@@ -540,7 +540,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                 }
             } else if (runS) {
                 // ---------------- setup step: the only place that writes tro/trd/inv
-                //   INIT : new ray (world space, sphere tests)      -> NEED
+                //   INIT : new ray (world space, sphere tests)      -> NEED, or straight into object 0 if that needs a transform
                 //   WORLD: world-space ray again                     -> NEED
                 //   SETUP: into object `obj` with a general matrix   -> its root
                 if (cur - RT_CUR_INIT <= RT_CUR_SETUP - RT_CUR_INIT) {
@@ -562,7 +562,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         wt.totRays++;
                         fetch_next_meta();
                     }
-                    const bool general = cur == RT_CUR_SETUP;
+                    // a new ray whose first object has a general transform goes into it in this very step
+                    const bool general = cur == RT_CUR_SETUP || (cur == RT_CUR_INIT && sc.objectCount > 0u && !((nxFlags & 1u) && plain));
                     if (general) {
                         const float4 r0 = sc.objInv[3 * obj], r1 = sc.objInv[3 * obj + 1], r2 = sc.objInv[3 * obj + 2];
                         trd = xform_dir_rows(r0, r1, r2, wd);
