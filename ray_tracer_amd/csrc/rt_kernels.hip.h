@@ -532,10 +532,24 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         cur = (cnt > take) ? (cur + take - (take << RT_LEAF_CNT_SHIFT)) : RT_CUR_NEED;
                     }
                     if (PIX) rayTri += jEnd - j; else wt.totTri += jEnd - j;
-                    for (; j < jEnd; j++) {
-                        const float4 a = sc.triPos[3 * (size_t)j], b = sc.triPos[3 * (size_t)j + 1], c = sc.triPos[3 * (size_t)j + 2];
-                        const TriHit h = tri_intersect(rt_v3(troXY.x, troXY.y, zOI.x), trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
-                        if (h.didHit && h.dst < best) { best = h.dst; bestObj = obj - 1; bestTri = j; }
+                    if (cnt != 0u) {
+                        // one or two triangles: both fetched before either is tested
+                        const uint32_t j1 = jEnd - 1u;
+                        const float4 a0 = sc.triPos[3 * (size_t)j], b0 = sc.triPos[3 * (size_t)j + 1], c0 = sc.triPos[3 * (size_t)j + 2];
+                        const float4 a1 = sc.triPos[3 * (size_t)j1], b1 = sc.triPos[3 * (size_t)j1 + 1], c1 = sc.triPos[3 * (size_t)j1 + 2];
+                        const rt_vec3 o = rt_v3(troXY.x, troXY.y, zOI.x);
+                        const TriHit h0 = tri_intersect(o, trd, f4xyz(a0), f4xyz(b0), f4xyz(c0), __float_as_uint(a0.w) != 0u);
+                        if (h0.didHit && h0.dst < best) { best = h0.dst; bestObj = obj - 1; bestTri = j; }
+                        if (j1 != j) {
+                            const TriHit h1 = tri_intersect(o, trd, f4xyz(a1), f4xyz(b1), f4xyz(c1), __float_as_uint(a1.w) != 0u);
+                            if (h1.didHit && h1.dst < best) { best = h1.dst; bestObj = obj - 1; bestTri = j1; }
+                        }
+                    } else {
+                        for (; j < jEnd; j++) {
+                            const float4 a = sc.triPos[3 * (size_t)j], b = sc.triPos[3 * (size_t)j + 1], c = sc.triPos[3 * (size_t)j + 2];
+                            const TriHit h = tri_intersect(rt_v3(troXY.x, troXY.y, zOI.x), trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
+                            if (h.didHit && h.dst < best) { best = h.dst; bestObj = obj - 1; bestTri = j; }
+                        }
                     }
                 }
             } else if (runS) {
