@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -25,7 +26,7 @@ struct DevBuf {
 
 struct EventPair { hipEvent_t a, b; };
 // device-side {index,triCount} of a mesh root, keyed by its reference node index
-struct RootInfo { uint32_t idx, cnt; };
+struct RootInfo { uint32_t idx, cnt; float lo[3], hi[3]; };
 
 }  // namespace
 
@@ -38,7 +39,7 @@ struct rt_ctx {
     // scene
     DevScene sc{};
     std::vector<DevBuf> sceneBufs;
-    DevBuf matBuf, sphereBuf, sphereMatBuf, objInvBuf, objFwdBuf, objMetaBuf;
+    DevBuf matBuf, sphereBuf, sphereMatBuf, objInvBuf, objFwdBuf, objMetaBuf, objBoxBuf;
     uint32_t maxLeafDepth = 0;
     std::vector<uint32_t> nodeRemap;          // reference node index -> device node index
     std::vector<RootInfo> rootOf;             // per reference node; idx = ~0u unless a mesh root
@@ -393,7 +394,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->sceneBufs) dev_free(b);
-    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->stateBuf,
+    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->stateBuf,
                       &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf, &c->waveTimeBuf})
         dev_free(*b);
     for (auto& e : c->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -452,6 +453,7 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
     RT_HIP(c, hipSetDevice(c->device));
     std::vector<float4> inv((size_t)std::max(n, 1u) * 3), fwd((size_t)std::max(n, 1u) * 3);
     std::vector<uint4> meta(std::max(n, 1u));
+    std::vector<float4> wbox((size_t)std::max(n, 1u) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
     for (uint32_t i = 0; i < n; i++) {
         float im[16];
         rt_mat4_inverse(o[i].transformMatrix, im);
@@ -469,12 +471,45 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
             const float qq[4] = {q.x, q.y, q.z, q.w};
             for (int k4 = 0; k4 < 4; k4++) isIdent = isIdent && (qq[k4] == ident[r4 * 4 + k4]);
         }
-        meta[i] = make_uint4(r.idx, r.cnt, o[i].materialIndex, isIdent ? 1u : 0u);
+        // World-space box of the object, padded: a ray that cannot reach it before its current closest hit cannot reach the
+        // object's root box in object space either, so the object is worth exactly the reference's two box tests on the root's
+        // children (or the root leaf's triangle tests) and no set-up. Padding 1e-3 of the box's size and position: four
+        // orders of magnitude above what the fp32 inverse and the two slab tests can disagree by.
+        uint32_t boxOk = 0;
+        if (!isIdent) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            bool finite = true;
+            for (int corner = 0; corner < 8; corner++) {
+                const double p[3] = {(corner & 1) ? r.hi[0] : r.lo[0], (corner & 2) ? r.hi[1] : r.lo[1], (corner & 4) ? r.hi[2] : r.lo[2]};
+                for (int d = 0; d < 3; d++) {
+                    const float* m = o[i].transformMatrix;
+                    const double w = (double)m[0 * 4 + d] * p[0] + (double)m[1 * 4 + d] * p[1] + (double)m[2 * 4 + d] * p[2] + (double)m[3 * 4 + d];
+                    finite = finite && std::isfinite(w);
+                    lo[d] = std::min(lo[d], w); hi[d] = std::max(hi[d], w);
+                }
+            }
+            for (int k4 = 0; k4 < 12; k4++) finite = finite && std::isfinite((&inv[3 * (size_t)i].x)[k4]);
+            if (finite) {
+                double pad = 1e-6;
+                for (int d = 0; d < 3; d++) pad = std::max(pad, 1e-3 * std::max(hi[d] - lo[d], std::max(std::fabs(lo[d]), std::fabs(hi[d]))));
+                wbox[2 * (size_t)i] = make_float4((float)(lo[0] - pad), (float)(lo[1] - pad), (float)(lo[2] - pad), 0.f);
+                wbox[2 * (size_t)i + 1] = make_float4((float)(hi[0] + pad), (float)(hi[1] + pad), (float)(hi[2] + pad), 0.f);
+                boxOk = 2u;
+            }
+        }
+        meta[i] = make_uint4(r.idx, r.cnt, o[i].materialIndex, (isIdent ? 1u : 0u) | boxOk);
+        {   // flags and root triangle count ride in the box's w components (one fetch per object in the skipping loop)
+            const uint32_t fl = meta[i].w, cn = r.cnt;
+            memcpy(&wbox[2 * (size_t)i].w, &fl, 4);
+            memcpy(&wbox[2 * (size_t)i + 1].w, &cn, 4);
+        }
     }
     int rc = upload(c, c->objInvBuf, inv.data(), inv.size() * sizeof(float4));
     if (rc) return rc;
     if ((rc = upload(c, c->objFwdBuf, fwd.data(), fwd.size() * sizeof(float4)))) return rc;
     if ((rc = upload(c, c->objMetaBuf, meta.data(), meta.size() * sizeof(uint4)))) return rc;
+    if ((rc = upload(c, c->objBoxBuf, wbox.data(), wbox.size() * sizeof(float4)))) return rc;
+    c->sc.objBox = (const float4*)c->objBoxBuf.p;
     c->sc.objInv = (const float4*)c->objInvBuf.p;
     c->sc.objFwd = (const float4*)c->objFwdBuf.p;
     c->sc.objMeta = (const uint4*)c->objMetaBuf.p;
@@ -561,13 +596,13 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
 
     // ---- deepest leaf per mesh decides the LDS stack size
     std::vector<RootInfo>& rootOf = c->rootOf;
-    rootOf.assign(nNodes, RootInfo{0xffffffffu, 0});
+    rootOf.assign(nNodes, RootInfo{0xffffffffu, 0, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
     uint32_t maxDepth = 0;
     {
         std::vector<std::pair<uint32_t, uint32_t>> st;
         for (uint32_t root : roots) {
             const BVHNode& rb = s->bvhNodes[root];
-            rootOf[root] = RootInfo{node_word(root), rb.triCount};
+            rootOf[root] = RootInfo{node_word(root), rb.triCount, {rb.boundsX[0], rb.boundsY[0], rb.boundsZ[0]}, {rb.boundsX[1], rb.boundsY[1], rb.boundsZ[1]}};
             st.clear();
             st.emplace_back(root, 0u);
             size_t visited = 0;
@@ -718,7 +753,11 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     // and scenes with short rays (few box tests per ray, measured on this context's earlier dispatches) go to the fused one.
     poll_ray_cost(c);
     const bool shortRays = c->boxPerRay >= 0.0 && c->boxPerRay < (double)c->fusedBelowBoxTests;
-    c->lastPipeline = c->pipeline >= 0 ? c->pipeline : ((nPixels < c->fusedBelowPixels || shortRays) ? 1 : 0);
+    // the longer the rays, the earlier the global queue of the multi-kernel pipeline pays: Sponza (157 box tests per ray)
+    // switches near 2.8 M pixels, Sponza + 16 dragons (213) near 1 M
+    double sizeLimit = (double)c->fusedBelowPixels;
+    if (c->boxPerRay > 160.0) sizeLimit = std::max(800000.0, sizeLimit - (c->boxPerRay - 160.0) * 34000.0);
+    c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (((double)nPixels < sizeLimit || shortRays) ? 1 : 0);
     if (c->lastPipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch
         rc = launch_fused(c, fp, fb);
         c->sc = saved;

@@ -46,7 +46,8 @@
 //   triNrm  : 3 x float4 per triangle   vertex normals; cold, read per hit only
 //   objInv  : 3 x float4 per object     rows of inverse(transformMatrix)[0..2]
 //   objFwd  : 3 x float4 per object     rows of transformMatrix[0..2]
-//   objMeta : uint4 per object          {rootIndex|pairIndex, rootTriCount, materialIndex, flags (bit 0: identity transform)}
+//   objMeta : uint4 per object          {rootIndex|pairIndex, rootTriCount, materialIndex, flags (bit 0: identity transform, bit 1: objBox valid)}
+//   objBox  : 2 x float4 per object     padded world-space box of a general-transform object
 //   mats    : 3 x float4 per material   {albedo, reflectance} {emission, strength} {ior,-,-,-}
 //   spheres : float4 {center, radius} + uint material
 struct DevScene {
@@ -58,6 +59,7 @@ struct DevScene {
     const float4* objInv;
     const float4* objFwd;
     const uint4* objMeta;
+    const float4* objBox;    // 2 x float4 per object: padded world-space box (general-transform objects, objMeta flag bit 1)
     const float4* mats;
     const float4* spheres;
     const uint32_t* sphereMat;
@@ -577,7 +579,33 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         fetch_next_meta();
                     }
                     // a new ray whose first object has a general transform goes into it in this very step
-                    const bool general = cur == RT_CUR_SETUP || (cur == RT_CUR_INIT && sc.objectCount > 0u && !((nxFlags & 1u) && plain));
+                    bool general = cur == RT_CUR_SETUP || (cur == RT_CUR_INIT && sc.objectCount > 0u && !((nxFlags & 1u) && plain));
+                    if (general && plain) {
+                        // General-transform objects the ray cannot reach before its closest hit so far are not entered: in
+                        // the reference such an object costs the two box tests on its root's children (its root leaf's triangle
+                        // tests) and nothing else; that is what is counted. (objBox: padded world box; plain: finite ray.)
+                        const rt_vec3 iw = rt_v3(1.f / wd.x, 1.f / wd.y, 1.f / wd.z);
+                        // two objects per trip, their boxes fetched together (lo.w = objMeta flags, hi.w = root triangle count)
+                        while (obj < sc.objectCount) {
+                            const uint32_t i1 = min(obj + 1u, sc.objectCount - 1u);
+                            const float4 a0 = sc.objBox[2 * obj], b0 = sc.objBox[2 * obj + 1], a1 = sc.objBox[2 * i1], b1 = sc.objBox[2 * i1 + 1];
+                            if ((__float_as_uint(a0.w) & 3u) != 2u) break;  // identity, or no usable box
+                            if (box_intersect(a0, b0, wo, iw) < best) break;
+                            const uint32_t c0 = __float_as_uint(b0.w);
+                            if (c0 == 0u) { if (PIX) rayBox += 2; else wt.totBox += 2; }
+                            else { if (PIX) rayTri += c0; else wt.totTri += c0; }
+                            obj++;
+                            if (obj >= sc.objectCount) break;
+                            if ((__float_as_uint(a1.w) & 3u) != 2u) break;
+                            if (box_intersect(a1, b1, wo, iw) < best) break;
+                            const uint32_t c1 = __float_as_uint(b1.w);
+                            if (c1 == 0u) { if (PIX) rayBox += 2; else wt.totBox += 2; }
+                            else { if (PIX) rayTri += c1; else wt.totTri += c1; }
+                            obj++;
+                        }
+                        fetch_next_meta();
+                        general = obj < sc.objectCount && !(nxFlags & 1u);
+                    }
                     if (general) {
                         const float4 r0 = sc.objInv[3 * obj], r1 = sc.objInv[3 * obj + 1], r2 = sc.objInv[3 * obj + 2];
                         trd = xform_dir_rows(r0, r1, r2, wd);
