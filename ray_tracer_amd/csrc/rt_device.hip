@@ -497,6 +497,11 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
                 boxOk = 2u;
             }
         }
+        if (isIdent && r.cnt == 0u) {  // exact root box: the rays' creators rule the object out with the traversal's own slab test
+            wbox[2 * (size_t)i] = make_float4(r.lo[0], r.lo[1], r.lo[2], 0.f);
+            wbox[2 * (size_t)i + 1] = make_float4(r.hi[0], r.hi[1], r.hi[2], 0.f);
+            boxOk = 4u;
+        }
         meta[i] = make_uint4(r.idx, r.cnt, o[i].materialIndex, (isIdent ? 1u : 0u) | boxOk);
         {   // flags and root triangle count ride in the box's w components (one fetch per object in the skipping loop)
             const uint32_t fl = meta[i].w, cn = r.cnt;
@@ -510,6 +515,9 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
     if ((rc = upload(c, c->objMetaBuf, meta.data(), meta.size() * sizeof(uint4)))) return rc;
     if ((rc = upload(c, c->objBoxBuf, wbox.data(), wbox.size() * sizeof(float4)))) return rc;
     c->sc.objBox = (const float4*)c->objBoxBuf.p;
+    c->sc.reachCount = 0;
+    for (uint32_t i = 0; i < std::min(n, 32u); i++)
+        if (meta[i].w & 4u) c->sc.reachCount = i + 1;
     c->sc.objInv = (const float4*)c->objInvBuf.p;
     c->sc.objFwd = (const float4*)c->objFwdBuf.p;
     c->sc.objMeta = (const uint4*)c->objMetaBuf.p;
@@ -742,6 +750,7 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     DevScene sc = c->sc;
     sc.sphereCount = td.sphereCount;
     sc.objectCount = td.objectCount;
+    sc.reachCount = std::min(sc.reachCount, sc.objectCount);  // the dispatch may use fewer objects than were uploaded
     DevScene saved = c->sc;
     c->sc = sc;
 

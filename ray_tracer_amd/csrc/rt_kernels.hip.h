@@ -59,11 +59,13 @@ struct DevScene {
     const float4* objInv;
     const float4* objFwd;
     const uint4* objMeta;
-    const float4* objBox;    // 2 x float4 per object: padded world-space box (general-transform objects, objMeta flag bit 1)
+    const float4* objBox;    // 2 x float4 per object: {lo.xyz, flags} {hi.xyz, root triangle count}; flags bit 0 identity transform,
+                             // bit 1 padded world-space box of a general-transform object, bit 2 exact root box of an identity object with an interior root
     const float4* mats;
     const float4* spheres;
     const uint32_t* sphereMat;
     uint32_t sphereCount, objectCount, materialCount, nodeCount, triCount;
+    uint32_t reachCount;     // objects (from 0, at most 32) worth testing for a ray's object mask: up to the last one with objBox flag bit 2
 };
 
 // ---------------------------------------------------------------- path state (SoA, one slot per pixel)
@@ -180,14 +182,48 @@ __device__ __forceinline__ SphereHit sphere_intersect(float4 s, rt_vec3 ro, rt_v
 // The sphere loop of calculateIntersections (raytrace.comp:282-287) for one ray. The kernels that
 // CREATE rays (k_raygen, k_shade) run it, with all lanes busy, and leave the result in the ray's hit
 // record as the starting "closest hit" of the traversal; k_trace_pw then only walks the objects.
-__device__ __forceinline__ float4 sphere_seed(const DevScene& sc, rt_vec3 ro, rt_vec3 rd) {
+__device__ __forceinline__ float box_intersect(float4 lo, float4 hi, rt_vec3 ro, rt_vec3 inv);
+
+// A ray that may use an identity-transform object's space as is: finite and non-zero direction, finite origin, no
+// negative zeros (multiplying by the identity matrix would turn -0 into +0 and change 1/dir's sign of infinity)
+__device__ __forceinline__ bool ray_is_plain(rt_vec3 wo, rt_vec3 wd) {
+    const uint32_t E = 0x7f800000u, M = 0x7fffffffu;
+    return ((rt_f2u(wd.x) & M) - 1u < E - 1u) && ((rt_f2u(wd.y) & M) - 1u < E - 1u) && ((rt_f2u(wd.z) & M) - 1u < E - 1u) &&
+           ((rt_f2u(wo.x) & M) < E) && ((rt_f2u(wo.y) & M) < E) && ((rt_f2u(wo.z) & M) < E) &&
+           rt_f2u(wo.x) != 0x80000000u && rt_f2u(wo.y) != 0x80000000u && rt_f2u(wo.z) != 0x80000000u;
+}
+
+// What the creator of a ray hands to the traversal (hit record of the ray's kind): the closest sphere hit (the shader's
+// sphere loop, raytrace.comp:282-287) and, in .z, the objects among the first 32 the ray has to enter at all. Bit i is
+// cleared when object i has an identity transform and an interior root and the ray misses the root's box (objBox holds it,
+// exactly): both of the root's children are then missed as well, the reference does its two box tests on them and moves
+// on, and so does the traversal — by adding 2 to the count (trace_wave: fetch_next_meta). On the Sponza stand-in a ray
+// misses 16 of the 26 material groups' boxes on average. Same slab arithmetic as the traversal's (1/dir, box_intersect).
+// boxes: the first min(32, objectCount) entries of objBox, wherever the caller keeps them (k_render_fused: in LDS)
+__device__ __forceinline__ uint32_t reach_mask_from(const float4* boxes, uint32_t n, rt_vec3 ro, rt_vec3 rd) {
+    uint32_t reach = 0xffffffffu;
+    if (ray_is_plain(ro, rd)) {
+        const rt_vec3 inv = rt_v3(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
+        for (uint32_t i = 0; i < n; i++) {
+            const float4 lo = boxes[2 * i], hi = boxes[2 * i + 1];
+            if ((__float_as_uint(lo.w) & 4u) && box_intersect(lo, hi, ro, inv) == RT_MISS_DST) reach &= ~(1u << i);
+        }
+    }
+    return reach;
+}
+__device__ __forceinline__ uint32_t reach_mask(const DevScene& sc, rt_vec3 ro, rt_vec3 rd) {
+    return reach_mask_from(sc.objBox, sc.reachCount, ro, rd);
+}
+
+// withMask false: the caller adds the mask later (k_render_fused does, outside shade_path, where registers are not scarce)
+__device__ __forceinline__ float4 sphere_seed(const DevScene& sc, rt_vec3 ro, rt_vec3 rd, bool withMask = true) {
     float best = RT_MISS_DST;
     uint32_t obj = RT_HIT_NONE;
     for (uint32_t i = 0; i < sc.sphereCount; i++) {
         SphereHit h = sphere_intersect(sc.spheres[i], ro, rd);
         if (h.didHit && h.dst < best) { best = h.dst; obj = RT_HIT_SPHERE | i; }
     }
-    return make_float4(best, __uint_as_float(obj), __uint_as_float(0u), 0.f);
+    return make_float4(best, __uint_as_float(obj), __uint_as_float(withMask ? reach_mask(sc, ro, rd) : 0xffffffffu), 0.f);
 }
 
 struct TriHit { bool didHit, frontFace; float dst, u, v, w; };
@@ -457,7 +493,15 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
 
     uint32_t thr = ta.fastLanes;
 
+    uint32_t reach = 0xffffffffu;  // objects (of the first 32) the ray has to enter, from its creator (sphere_seed)
+
     auto fetch_next_meta = [&]() {
+        if (obj < 32u) {  // the objects in between are worth their two box tests and nothing else
+            const uint32_t m = reach >> obj;
+            const uint32_t skip = m ? (uint32_t)__ffs((int)m) - 1u : 32u - obj;
+            if (PIX) rayBox += 2u * skip; else wt.totBox += 2u * skip;
+            obj += skip;
+        }
         if (obj < sc.objectCount) {
             const uint4 m = sc.objMeta[obj];
             nxW = m.x; nxFlags = m.w;
@@ -568,11 +612,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         // the ray's creator already ran the sphere loop (sphere_seed)
                         const float4 seed = ps.hit(kind)[slot];
                         best = seed.x; bestObj = __float_as_uint(seed.y); bestTri = 0;
-                        // finite and non-zero direction, finite origin without negative zeros
-                        const uint32_t E = 0x7f800000u, M = 0x7fffffffu;
-                        plain = ((rt_f2u(wd.x) & M) - 1u < E - 1u) && ((rt_f2u(wd.y) & M) - 1u < E - 1u) && ((rt_f2u(wd.z) & M) - 1u < E - 1u) &&
-                                ((rt_f2u(wo.x) & M) < E) && ((rt_f2u(wo.y) & M) < E) && ((rt_f2u(wo.z) & M) < E) &&
-                                rt_f2u(wo.x) != 0x80000000u && rt_f2u(wo.y) != 0x80000000u && rt_f2u(wo.z) != 0x80000000u;
+                        plain = ray_is_plain(wo, wd);
+                        reach = __float_as_uint(seed.z);
                         obj = 0; sp = 0;
                         if (PIX) { rayBox = 0; rayTri = 0; }
                         wt.totRays++;
@@ -870,7 +911,7 @@ struct ShadeArgs {
 // its next rays. Outputs: alive (a main ray was emitted), wantAux (and two probe rays), refRays (the
 // shader's calculateIntersections calls for this segment), nPaths (1 if a sample finished).
 __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& ps, const FrameParams& fp, uint32_t slot, bool& alive,
-                                           bool& wantAux, uint32_t& refRays, uint32_t& nPaths) {
+                                           bool& wantAux, uint32_t& refRays, uint32_t& nPaths, bool withMask = true) {
     rt_vec3 auxOrigin = rt_v3(0, 0, 0), auxL = auxOrigin, auxC = auxOrigin;  // probe rays of this bounce (diffuse only)
     const float4 sO = ps.rayO()[slot], sD = ps.rayD()[slot], sA = ps.att()[slot], sT = ps.total()[slot], sDi = ps.direct()[slot];
     const float4 hM = ps.hit(RAY_MAIN)[slot];
@@ -1035,10 +1076,10 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
     }
 
     if (alive) {
-        ps.hit(RAY_MAIN)[slot] = sphere_seed(sc, ro, rd);
+        ps.hit(RAY_MAIN)[slot] = sphere_seed(sc, ro, rd, withMask);
         if (wantAux) {
-            ps.hit(RAY_NEE)[slot] = sphere_seed(sc, auxOrigin, auxL);
-            ps.hit(RAY_PROBE)[slot] = sphere_seed(sc, auxOrigin, auxC);
+            ps.hit(RAY_NEE)[slot] = sphere_seed(sc, auxOrigin, auxL, withMask);
+            ps.hit(RAY_PROBE)[slot] = sphere_seed(sc, auxOrigin, auxC, withMask);
         }
         ps.rayO()[slot] = mk4(ro, misW);
         ps.rayD()[slot] = mk4u(rd, state);
@@ -1183,6 +1224,10 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
     const FusedArgs& fa = ka.fa;
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];
     __shared__ uint32_t s_list[RT_BLOCK / RT_WAVE][3 * RT_WAVE];
+    __shared__ float4 s_box[64];  // objBox of the first 32 objects: the rays' object masks are computed from here (reach_mask_from)
+    const uint32_t nBox = sc.reachCount;
+    if (threadIdx.x < 2u * nBox) s_box[threadIdx.x] = sc.objBox[threadIdx.x];
+    __syncthreads();
     const uint32_t wv = threadIdx.x / RT_WAVE;
     uint32_t* stack = s_stack + wv * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
     uint32_t* list = s_list[wv];
@@ -1227,8 +1272,23 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
             if (alive) {
                 kq = opaque_kernarg<FusedKernArgs>();
                 fq = &kq->fp; sq = &kq->sc;
-                shade_path(*sq, ps, *fq, slot, nowAlive, wantAux, refRays, nPaths);
+                shade_path(*sq, ps, *fq, slot, nowAlive, wantAux, refRays, nPaths, false);
                 segTot++;
+                if (nowAlive && nBox) {
+                    // the new rays' object masks (sphere_seed), here rather than inside shade_path: its registers are spilling already
+                    float4 sd = ps.hit(RAY_MAIN)[slot];
+                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, f4xyz(ps.rayO()[slot]), f4xyz(ps.rayD()[slot])));
+                    ps.hit(RAY_MAIN)[slot] = sd;
+                    if (wantAux) {
+                        const rt_vec3 ao = f4xyz(ps.auxO()[slot]);
+                        sd = ps.hit(RAY_NEE)[slot];
+                        sd.z = __uint_as_float(reach_mask_from(s_box, nBox, ao, f4xyz(ps.auxDL()[slot])));
+                        ps.hit(RAY_NEE)[slot] = sd;
+                        sd = ps.hit(RAY_PROBE)[slot];
+                        sd.z = __uint_as_float(reach_mask_from(s_box, nBox, ao, f4xyz(ps.auxDC()[slot])));
+                        ps.hit(RAY_PROBE)[slot] = sd;
+                    }
+                }
             }
             alive = nowAlive;
             refTot += refRays;
