@@ -494,7 +494,7 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
                 for (int d = 0; d < 3; d++) pad = std::max(pad, 1e-3 * std::max(hi[d] - lo[d], std::max(std::fabs(lo[d]), std::fabs(hi[d]))));
                 wbox[2 * (size_t)i] = make_float4((float)(lo[0] - pad), (float)(lo[1] - pad), (float)(lo[2] - pad), 0.f);
                 wbox[2 * (size_t)i + 1] = make_float4((float)(hi[0] + pad), (float)(hi[1] + pad), (float)(hi[2] + pad), 0.f);
-                boxOk = 2u;
+                boxOk = r.cnt == 0u ? 6u : 2u;  // interior root: the rays' creators may rule the object out as well (bit 2)
             }
         }
         if (isIdent && r.cnt == 0u) {  // exact root box: the rays' creators rule the object out with the traversal's own slab test

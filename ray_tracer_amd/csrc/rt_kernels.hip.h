@@ -60,7 +60,8 @@ struct DevScene {
     const float4* objFwd;
     const uint4* objMeta;
     const float4* objBox;    // 2 x float4 per object: {lo.xyz, flags} {hi.xyz, root triangle count}; flags bit 0 identity transform,
-                             // bit 1 padded world-space box of a general-transform object, bit 2 exact root box of an identity object with an interior root
+                             // bit 1 padded world-space box of a general-transform object, bit 2 the box may clear the object's bit in a ray's object mask
+                             // (identity object: its exact root box; general object: the padded world box; interior roots only)
     const float4* mats;
     const float4* spheres;
     const uint32_t* sphereMat;
@@ -495,18 +496,25 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
 
     uint32_t reach = 0xffffffffu;  // objects (of the first 32) the ray has to enter, from its creator (sphere_seed)
 
+    // Called right after `obj` moved past the object that is being entered: obj - 1 is the object under traversal. The
+    // objects after it that the ray's mask rules out are jumped over here (two box tests each, nothing else), and how many
+    // were is kept in nxFlags[15:8], so that the object under traversal is still obj - 1 - skipped (cur_object()).
     auto fetch_next_meta = [&]() {
-        if (obj < 32u) {  // the objects in between are worth their two box tests and nothing else
+        uint32_t skip = 0;
+        if (obj < 32u) {
             const uint32_t m = reach >> obj;
-            const uint32_t skip = m ? (uint32_t)__ffs((int)m) - 1u : 32u - obj;
+            skip = m ? (uint32_t)__ffs((int)m) - 1u : 32u - obj;
             if (PIX) rayBox += 2u * skip; else wt.totBox += 2u * skip;
             obj += skip;
         }
+        uint32_t fl = 0;
         if (obj < sc.objectCount) {
             const uint4 m = sc.objMeta[obj];
-            nxW = m.x; nxFlags = m.w;
+            nxW = m.x; fl = m.w & 0xffu;
         }
+        nxFlags = fl | (skip << 8);
     };
+    auto cur_object = [&]() { return obj - 1u - (nxFlags >> 8); };
 
     for (;;) {
         const unsigned long long tRound = STATS ? clock64() : 0ull;
@@ -585,16 +593,16 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         const float4 a1 = sc.triPos[3 * (size_t)j1], b1 = sc.triPos[3 * (size_t)j1 + 1], c1 = sc.triPos[3 * (size_t)j1 + 2];
                         const rt_vec3 o = rt_v3(troXY.x, troXY.y, zOI.x);
                         const TriHit h0 = tri_intersect(o, trd, f4xyz(a0), f4xyz(b0), f4xyz(c0), __float_as_uint(a0.w) != 0u);
-                        if (h0.didHit && h0.dst < best) { best = h0.dst; bestObj = obj - 1; bestTri = j; }
+                        if (h0.didHit && h0.dst < best) { best = h0.dst; bestObj = cur_object(); bestTri = j; }
                         if (j1 != j) {
                             const TriHit h1 = tri_intersect(o, trd, f4xyz(a1), f4xyz(b1), f4xyz(c1), __float_as_uint(a1.w) != 0u);
-                            if (h1.didHit && h1.dst < best) { best = h1.dst; bestObj = obj - 1; bestTri = j1; }
+                            if (h1.didHit && h1.dst < best) { best = h1.dst; bestObj = cur_object(); bestTri = j1; }
                         }
                     } else {
                         for (; j < jEnd; j++) {
                             const float4 a = sc.triPos[3 * (size_t)j], b = sc.triPos[3 * (size_t)j + 1], c = sc.triPos[3 * (size_t)j + 2];
                             const TriHit h = tri_intersect(rt_v3(troXY.x, troXY.y, zOI.x), trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
-                            if (h.didHit && h.dst < best) { best = h.dst; bestObj = obj - 1; bestTri = j; }
+                            if (h.didHit && h.dst < best) { best = h.dst; bestObj = cur_object(); bestTri = j; }
                         }
                     }
                 }

@@ -403,3 +403,20 @@ def test_degenerate_and_coincident_triangles(renderer):
     W, H = 96, 72
     pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3)
     _check(*_render_both(renderer, s, pc, W, H))
+
+
+def test_many_separate_identity_objects_of_different_materials(renderer):
+    """Eight small meshes with identity transforms, far apart and each of another material, inside the Cornell box: most
+    rays miss most of their root boxes, so the traversal jumps over runs of objects (the rays' object masks) and must still
+    credit every hit to the object it is in and count the skipped objects' box tests."""
+    s = engine.Scene()
+    s.prepare_storage_buffers()
+    glow = s.add_material(engine.default_material(albedo=(0.2, 0.3, 0.9), emissionColor=(0.2, 0.4, 1.0), emissionStrength=1.5))
+    teal = s.add_material(engine.default_material(albedo=(0.1, 0.8, 0.7)))
+    mats = [0, 1, 2, 4, 5, glow, teal, 1]
+    for k in range(8):
+        pos, nrm = scenes.blob(180 + 40 * k, seed=10 + k, radius=0.13, center=(-0.75 + 0.5 * (k % 4), -0.75 + 0.9 * (k // 4), -0.5 + 0.3 * (k % 3)))
+        s.add_mesh(f"blob{k}", pos, nrm, engine.placement(), mats[k])
+    W, H = 128, 96
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3, bounceLimit=6)
+    _check(*_render_both(renderer, s, pc, W, H))
