@@ -39,7 +39,7 @@ struct rt_ctx {
     // scene
     DevScene sc{};
     std::vector<DevBuf> sceneBufs;
-    DevBuf matBuf, sphereBuf, sphereMatBuf, objInvBuf, objFwdBuf, objMetaBuf, objBoxBuf;
+    DevBuf matBuf, sphereBuf, sphereMatBuf, objInvBuf, objFwdBuf, objMetaBuf, objBoxBuf, objSkipBuf, maskBoxBuf;
     uint32_t maxLeafDepth = 0;
     std::vector<uint32_t> nodeRemap;          // reference node index -> device node index
     std::vector<RootInfo> rootOf;             // per reference node; idx = ~0u unless a mesh root
@@ -87,6 +87,8 @@ struct rt_ctx {
     int wSetupFused = 16, wLeafFused = 24;  // vote weights of the fused pipeline (short private lists: leaves and set-ups sooner)
     double bvhBuildMs = 0.0; // last rt_bvh_build
     int fastShare = 10;     // sixteenths of the live lanes that suffice to skip the vote (0 = fixed count only): -1..-2 % everywhere
+    bool cull = false;      // kernels with the object-skipping code (CULL) for this scene
+    int maskIdentity = 0;   // identity-transform objects in the rays' object masks too (rt_update_objects reads it)
     int scatter = -1;       // fused pipeline: blocks made of chunks of this many slots from all over the tile; 0 = neighbouring pixels; -1 = auto
     int batchPixels = 0;    // fused pipeline: pixels per wave-private block (0 = chosen per launch)
     int batchFixed = 80;    // ... and the fixed part of a block's cost in the chooser, in pixel units
@@ -173,11 +175,11 @@ int ensure_state(rt_ctx* c, uint32_t nPixels) {
     return 0;
 }
 
-template <int STACK, bool OVF>
+template <int STACK, bool OVF, bool CULL>
 int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     int perCU = c->blocksPerCU;
     if (perCU <= 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false, CULL>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
     }
     uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
     uint32_t blocks = std::min((maxRays + RT_BLOCK - 1) / RT_BLOCK, resident);
@@ -199,9 +201,9 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
                    ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), waveTimes, overflow};
     // per-ray counters are only needed for the pixel heat maps (debug >= 0) and rt_trace_rays
     const bool pix = c->pixStats || ta.perRayBox;
-    if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
-    else if (pix) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
-    else hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, true, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    else if (pix) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, false, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    else hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
     return 0;
 }
 
@@ -226,11 +228,11 @@ uint32_t fused_batch_pixels(const rt_ctx* c, uint32_t nPixels, uint32_t waves) {
     return best;
 }
 
-template <int STACK, bool OVF>
+template <int STACK, bool OVF, bool CULL>
 int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
     int perCU = c->blocksPerCU;
     if (perCU <= 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_render_fused<STACK, OVF, false>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_render_fused<STACK, OVF, false, CULL>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
     }
     const uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
     uint32_t batchPixels = fused_batch_pixels(c, fp.nPixels, resident * (RT_BLOCK / RT_WAVE));
@@ -264,8 +266,8 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
     FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, wLeaf, fastLanes, batchPixels, g, (uint32_t)c->fastShare, waveTimes};
     c->lastBatchPixels = (int)batchPixels;
     const FusedKernArgs ka{c->sc, c->ps, fp, fa};
-    if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
-    else hipLaunchKernelGGL((k_render_fused<STACK, OVF, false>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
+    if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
+    else hipLaunchKernelGGL((k_render_fused<STACK, OVF, false, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
     RT_HIP(c, hipGetLastError());
     return 0;
 }
@@ -284,12 +286,20 @@ int launch_fused(rt_ctx* c, const FrameParams& fp, float4* fb) {
     }
     const uint32_t d = c->maxLeafDepth, cap = (uint32_t)c->ldsStackCap;
     int rc;
-    if (d <= 8) rc = launch_fused_t<8, false>(c, fp, fb);
-    else if (cap < 16) rc = launch_fused_t<8, true>(c, fp, fb);
-    else if (d <= 16) rc = launch_fused_t<16, false>(c, fp, fb);
-    else if (cap < 24) rc = launch_fused_t<16, true>(c, fp, fb);
-    else if (d <= 24) rc = launch_fused_t<24, false>(c, fp, fb);
-    else rc = launch_fused_t<24, true>(c, fp, fb);
+    if (c->cull) {
+        if (d <= 8) rc = launch_fused_t<8, false, true>(c, fp, fb);
+        else if (cap < 16) rc = launch_fused_t<8, true, true>(c, fp, fb);
+        else if (d <= 16) rc = launch_fused_t<16, false, true>(c, fp, fb);
+        else if (cap < 24) rc = launch_fused_t<16, true, true>(c, fp, fb);
+        else if (d <= 24) rc = launch_fused_t<24, false, true>(c, fp, fb);
+        else rc = launch_fused_t<24, true, true>(c, fp, fb);
+    }
+    else if (d <= 8) rc = launch_fused_t<8, false, false>(c, fp, fb);
+    else if (cap < 16) rc = launch_fused_t<8, true, false>(c, fp, fb);
+    else if (d <= 16) rc = launch_fused_t<16, false, false>(c, fp, fb);
+    else if (cap < 24) rc = launch_fused_t<16, true, false>(c, fp, fb);
+    else if (d <= 24) rc = launch_fused_t<24, false, false>(c, fp, fb);
+    else rc = launch_fused_t<24, true, false>(c, fp, fb);
     if (rc) return rc;
     if (ev) RT_HIP(c, hipEventRecord(ev->b, c->stream));
     c->traceLaunchesTotal++;
@@ -327,12 +337,20 @@ int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
         else launch_v0_t<64>(c, maxRays, ta);
     } else {  // persistent waves; at most 24 entries in LDS, deeper ones in the overflow buffer
         const uint32_t cap = (uint32_t)c->ldsStackCap;
-        if (d <= 8) rc = launch_pw_t<8, false>(c, maxRays, ta);
-        else if (cap < 16) rc = launch_pw_t<8, true>(c, maxRays, ta);
-        else if (d <= 16) rc = launch_pw_t<16, false>(c, maxRays, ta);
-        else if (cap < 24) rc = launch_pw_t<16, true>(c, maxRays, ta);
-        else if (d <= 24) rc = launch_pw_t<24, false>(c, maxRays, ta);
-        else rc = launch_pw_t<24, true>(c, maxRays, ta);
+        if (c->cull) {
+            if (d <= 8) rc = launch_pw_t<8, false, true>(c, maxRays, ta);
+            else if (cap < 16) rc = launch_pw_t<8, true, true>(c, maxRays, ta);
+            else if (d <= 16) rc = launch_pw_t<16, false, true>(c, maxRays, ta);
+            else if (cap < 24) rc = launch_pw_t<16, true, true>(c, maxRays, ta);
+            else if (d <= 24) rc = launch_pw_t<24, false, true>(c, maxRays, ta);
+            else rc = launch_pw_t<24, true, true>(c, maxRays, ta);
+        }
+        else if (d <= 8) rc = launch_pw_t<8, false, false>(c, maxRays, ta);
+        else if (cap < 16) rc = launch_pw_t<8, true, false>(c, maxRays, ta);
+        else if (d <= 16) rc = launch_pw_t<16, false, false>(c, maxRays, ta);
+        else if (cap < 24) rc = launch_pw_t<16, true, false>(c, maxRays, ta);
+        else if (d <= 24) rc = launch_pw_t<24, false, false>(c, maxRays, ta);
+        else rc = launch_pw_t<24, true, false>(c, maxRays, ta);
     }
     if (rc) return rc;
     RT_HIP(c, hipGetLastError());
@@ -394,7 +412,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->sceneBufs) dev_free(b);
-    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->stateBuf,
+    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->stateBuf,
                       &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf, &c->waveTimeBuf})
         dev_free(*b);
     for (auto& e : c->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -454,6 +472,7 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
     std::vector<float4> inv((size_t)std::max(n, 1u) * 3), fwd((size_t)std::max(n, 1u) * 3);
     std::vector<uint4> meta(std::max(n, 1u));
     std::vector<float4> wbox((size_t)std::max(n, 1u) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+    uint32_t nGeneral = 0;
     for (uint32_t i = 0; i < n; i++) {
         float im[16];
         rt_mat4_inverse(o[i].transformMatrix, im);
@@ -476,6 +495,7 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
         // children (or the root leaf's triangle tests) and no set-up. Padding 1e-3 of the box's size and position: four
         // orders of magnitude above what the fp32 inverse and the two slab tests can disagree by.
         uint32_t boxOk = 0;
+        nGeneral += isIdent ? 0u : 1u;
         if (!isIdent) {
             double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
             bool finite = true;
@@ -494,12 +514,12 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
                 for (int d = 0; d < 3; d++) pad = std::max(pad, 1e-3 * std::max(hi[d] - lo[d], std::max(std::fabs(lo[d]), std::fabs(hi[d]))));
                 wbox[2 * (size_t)i] = make_float4((float)(lo[0] - pad), (float)(lo[1] - pad), (float)(lo[2] - pad), 0.f);
                 wbox[2 * (size_t)i + 1] = make_float4((float)(hi[0] + pad), (float)(hi[1] + pad), (float)(hi[2] + pad), 0.f);
-                boxOk = r.cnt == 0u ? 6u : 2u;  // interior root: the rays' creators may rule the object out as well (bit 2)
+                boxOk = 6u;  // the rays' creators may rule the object out as well (bit 2)
             }
         }
-        if (isIdent && r.cnt == 0u) {  // exact root box: the rays' creators rule the object out with the traversal's own slab test
-            wbox[2 * (size_t)i] = make_float4(r.lo[0], r.lo[1], r.lo[2], 0.f);
-            wbox[2 * (size_t)i + 1] = make_float4(r.hi[0], r.hi[1], r.hi[2], 0.f);
+        if (isIdent && c->maskIdentity) {  // exact root box: the rays' creators could rule the object out with the traversal's own
+            wbox[2 * (size_t)i] = make_float4(r.lo[0], r.lo[1], r.lo[2], 0.f);       // slab test. Off by default: measured, the rounds
+            wbox[2 * (size_t)i + 1] = make_float4(r.hi[0], r.hi[1], r.hi[2], 0.f);   // this saves are the cheap ones (profiles/README.md)
             boxOk = 4u;
         }
         meta[i] = make_uint4(r.idx, r.cnt, o[i].materialIndex, (isIdent ? 1u : 0u) | boxOk);
@@ -515,9 +535,33 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
     if ((rc = upload(c, c->objMetaBuf, meta.data(), meta.size() * sizeof(uint4)))) return rc;
     if ((rc = upload(c, c->objBoxBuf, wbox.data(), wbox.size() * sizeof(float4)))) return rc;
     c->sc.objBox = (const float4*)c->objBoxBuf.p;
+    // the objects (of the first 32) a ray's creator tests for the ray's object mask, compact: {lo.xyz, object index} {hi.xyz, -}
+    std::vector<float4> maskBox(64, make_float4(0.f, 0.f, 0.f, 0.f));
     c->sc.reachCount = 0;
     for (uint32_t i = 0; i < std::min(n, 32u); i++)
-        if (meta[i].w & 4u) c->sc.reachCount = i + 1;
+        if (meta[i].w & 4u) {
+            const uint32_t k = c->sc.reachCount++;
+            maskBox[2 * k] = wbox[2 * (size_t)i]; maskBox[2 * k + 1] = wbox[2 * (size_t)i + 1];
+            memcpy(&maskBox[2 * k].w, &i, 4);
+        }
+    // one general-transform object among identity ones (Sponza's emitter) does not pay for either mechanism: measured +3 % and
+    // +8..19 % on that scene; from two on they do (Cornell + model: -5..-13 %)
+    c->cull = nGeneral >= 2 || (c->maskIdentity && c->sc.reachCount);
+    if (!c->cull) c->sc.reachCount = 0;
+    if ((rc = upload(c, c->maskBoxBuf, maskBox.data(), maskBox.size() * sizeof(float4)))) return rc;
+    c->sc.maskBox = (const float4*)c->maskBoxBuf.p;
+    // what the reference spends on objects [0, i) when a ray misses them all: two box tests per interior root, the root's
+    // triangles per leaf root. A run of skipped objects costs the difference of two entries (trace_wave: fetch_next_meta).
+    std::vector<uint2> skipCost(33, make_uint2(0u, 0u));
+    for (uint32_t i = 0; i < 32u; i++) {
+        skipCost[i + 1] = skipCost[i];
+        if (i < n) {
+            if (meta[i].y == 0u) skipCost[i + 1].x += 2u;
+            else skipCost[i + 1].y += meta[i].y;
+        }
+    }
+    if ((rc = upload(c, c->objSkipBuf, skipCost.data(), skipCost.size() * sizeof(uint2)))) return rc;
+    c->sc.objSkipCost = (const uint2*)c->objSkipBuf.p;
     c->sc.objInv = (const float4*)c->objInvBuf.p;
     c->sc.objFwd = (const float4*)c->objFwdBuf.p;
     c->sc.objMeta = (const uint4*)c->objMetaBuf.p;
@@ -750,7 +794,7 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     DevScene sc = c->sc;
     sc.sphereCount = td.sphereCount;
     sc.objectCount = td.objectCount;
-    sc.reachCount = std::min(sc.reachCount, sc.objectCount);  // the dispatch may use fewer objects than were uploaded
+    if (sc.objectCount < c->sc.objectCount) sc.reachCount = 0;  // a dispatch with fewer objects than were uploaded: no masks
     DevScene saved = c->sc;
     c->sc = sc;
 
@@ -956,6 +1000,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "mk_w_setup") { if (value < 1 || value > 512) return c->fail("mk_w_setup: 1..512"); c->wSetup = value; }
     else if (k == "mk_w_leaf") { if (value < 1 || value > 512) return c->fail("mk_w_leaf: 1..512"); c->wLeaf = value; }
     else if (k == "tile_slots") { c->tileSlots = value != 0; }
+    else if (k == "mask_identity") { c->maskIdentity = value != 0; }
     else if (k == "fast_share") { if (value < 0 || value > 16) return c->fail("fast_share: 0..16"); c->fastShare = value; }
     else if (k == "scatter") { if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return c->fail("scatter: -1 (auto), 0, 1, 2, 4, 8 or 16"); c->scatter = value; }
     else if (k == "batch_pixels") { if (value < 0 || value > (int)RT_WAVE) return c->fail("batch_pixels must be 0 (auto) .. 64"); c->batchPixels = value; }

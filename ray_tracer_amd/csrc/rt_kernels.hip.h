@@ -61,12 +61,14 @@ struct DevScene {
     const uint4* objMeta;
     const float4* objBox;    // 2 x float4 per object: {lo.xyz, flags} {hi.xyz, root triangle count}; flags bit 0 identity transform,
                              // bit 1 padded world-space box of a general-transform object, bit 2 the box may clear the object's bit in a ray's object mask
-                             // (identity object: its exact root box; general object: the padded world box; interior roots only)
+                             // (identity object: its exact root box; general object: the padded world box)
     const float4* mats;
     const float4* spheres;
     const uint32_t* sphereMat;
     uint32_t sphereCount, objectCount, materialCount, nodeCount, triCount;
-    uint32_t reachCount;     // objects (from 0, at most 32) worth testing for a ray's object mask: up to the last one with objBox flag bit 2
+    const float4* maskBox;   // reachCount x 2 float4: the objects a ray's creator tests for the ray's object mask (reach_mask_from)
+    const uint2* objSkipCost; // 33 entries: {box tests, triangle tests} the reference spends on objects [0, i) when a ray misses them all
+    uint32_t reachCount;     // entries of maskBox
 };
 
 // ---------------------------------------------------------------- path state (SoA, one slot per pixel)
@@ -200,20 +202,20 @@ __device__ __forceinline__ bool ray_is_plain(rt_vec3 wo, rt_vec3 wd) {
 // exactly): both of the root's children are then missed as well, the reference does its two box tests on them and moves
 // on, and so does the traversal — by adding 2 to the count (trace_wave: fetch_next_meta). On the Sponza stand-in a ray
 // misses 16 of the 26 material groups' boxes on average. Same slab arithmetic as the traversal's (1/dir, box_intersect).
-// boxes: the first min(32, objectCount) entries of objBox, wherever the caller keeps them (k_render_fused: in LDS)
+// boxes: DevScene::maskBox, wherever the caller keeps it (k_render_fused: in LDS): n objects {lo.xyz, object index} {hi.xyz, -}
 __device__ __forceinline__ uint32_t reach_mask_from(const float4* boxes, uint32_t n, rt_vec3 ro, rt_vec3 rd) {
     uint32_t reach = 0xffffffffu;
-    if (ray_is_plain(ro, rd)) {
+    if (n && ray_is_plain(ro, rd)) {
         const rt_vec3 inv = rt_v3(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
-        for (uint32_t i = 0; i < n; i++) {
-            const float4 lo = boxes[2 * i], hi = boxes[2 * i + 1];
-            if ((__float_as_uint(lo.w) & 4u) && box_intersect(lo, hi, ro, inv) == RT_MISS_DST) reach &= ~(1u << i);
+        for (uint32_t k = 0; k < n; k++) {
+            const float4 lo = boxes[2 * k], hi = boxes[2 * k + 1];
+            if (box_intersect(lo, hi, ro, inv) == RT_MISS_DST) reach &= ~(1u << __float_as_uint(lo.w));
         }
     }
     return reach;
 }
 __device__ __forceinline__ uint32_t reach_mask(const DevScene& sc, rt_vec3 ro, rt_vec3 rd) {
-    return reach_mask_from(sc.objBox, sc.reachCount, ro, rd);
+    return reach_mask_from(sc.maskBox, sc.reachCount, ro, rd);
 }
 
 // withMask false: the caller adds the mask later (k_render_fused does, outside shade_path, where registers are not scarce)
@@ -463,6 +465,9 @@ struct WaveTotals {
 // OVF: the BVH is deeper than STACK; entries beyond the LDS part live in a global overflow buffer
 // (rarely touched: the stack only holds far siblings), so deep trees keep the occupancy of shallow ones.
 // LOCAL: the rays come from the wave's own list in LDS (k_render_fused) instead of the global queue.
+// CULL: objects a ray cannot reach are skipped at the cost the reference has for them (the ray's object mask from its creator,
+// and the set-up step's loop over general-transform objects); compiled in only for scenes with at least two general-transform
+// objects: its mere presence costs an identity-only scene like Sponza 3 % (k_trace_pw) to 10 % (k_render_fused).
 //
 // Instruction issue, scalar and vector alike, is what bounds this loop (measured: ~110 VALU +
 // ~100 SALU + 16 branches per round kept both issue ports ~70 % busy while the L1 and L2 idled;
@@ -471,7 +476,7 @@ struct WaveTotals {
 // goes straight to the interior step; pushes and pops are unconditional LDS accesses with
 // predicated pointer updates; the full vote, the refill and the leaf / setup steps live on a slow
 // path that is only entered when fewer than `fastLanes` lanes are at interior nodes.
-template <int STACK, bool OVF, bool PIX, bool STATS, bool LOCAL>
+template <int STACK, bool OVF, bool PIX, bool STATS, bool LOCAL, bool CULL>
 __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& ps, const TracePwArgs& ta, uint32_t* stack, uint32_t* ovf,
                                            size_t ovfStride, const uint32_t* localList, uint32_t n, WaveTotals& wt) {
     uint32_t cur = RT_CUR_IDLE;
@@ -501,10 +506,13 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
     // were is kept in nxFlags[15:8], so that the object under traversal is still obj - 1 - skipped (cur_object()).
     auto fetch_next_meta = [&]() {
         uint32_t skip = 0;
-        if (obj < 32u) {
+        if (CULL && obj < 32u) {
             const uint32_t m = reach >> obj;
             skip = m ? (uint32_t)__ffs((int)m) - 1u : 32u - obj;
-            if (PIX) rayBox += 2u * skip; else wt.totBox += 2u * skip;
+            if (skip) {
+                const uint2 c0 = sc.objSkipCost[obj], c1 = sc.objSkipCost[obj + skip];
+                if (PIX) { rayBox += c1.x - c0.x; rayTri += c1.y - c0.y; } else { wt.totBox += c1.x - c0.x; wt.totTri += c1.y - c0.y; }
+            }
             obj += skip;
         }
         uint32_t fl = 0;
@@ -512,9 +520,9 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
             const uint4 m = sc.objMeta[obj];
             nxW = m.x; fl = m.w & 0xffu;
         }
-        nxFlags = fl | (skip << 8);
+        nxFlags = CULL ? (fl | (skip << 8)) : fl;
     };
-    auto cur_object = [&]() { return obj - 1u - (nxFlags >> 8); };
+    auto cur_object = [&]() { return CULL ? obj - 1u - (nxFlags >> 8) : obj - 1u; };
 
     for (;;) {
         const unsigned long long tRound = STATS ? clock64() : 0ull;
@@ -629,7 +637,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     }
                     // a new ray whose first object has a general transform goes into it in this very step
                     bool general = cur == RT_CUR_SETUP || (cur == RT_CUR_INIT && sc.objectCount > 0u && !((nxFlags & 1u) && plain));
-                    if (general && plain) {
+                    if (CULL && general && plain) {
                         // General-transform objects the ray cannot reach before its closest hit so far are not entered: in
                         // the reference such an object costs the two box tests on its root's children (its root leaf's triangle
                         // tests) and nothing else; that is what is counted. (objBox: padded world box; plain: finite ray.)
@@ -740,7 +748,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
 
 }
 
-template <int STACK, bool OVF, bool PIX, bool STATS>
+template <int STACK, bool OVF, bool PIX, bool STATS, bool CULL>
 __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];  // +1: pushes are unconditional
     uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
@@ -749,7 +757,7 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
     const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
     WaveTotals wt;
     const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
-    trace_wave<STACK, OVF, PIX, STATS, false>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt);
+    trace_wave<STACK, OVF, PIX, STATS, false, CULL>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt);
 
     if (STATS && lane_id() == 0) {
         const size_t w = (size_t)blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;
@@ -1224,7 +1232,7 @@ struct FusedKernArgs {  // the whole kernel-argument segment, so that it can be 
     FusedArgs fa;
 };
 
-template <int STACK, bool OVF, bool PIX>
+template <int STACK, bool OVF, bool PIX, bool CULL>
 __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) {
     const DevScene& sc = ka.sc;
     const PathState& ps = ka.ps;
@@ -1233,8 +1241,8 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];
     __shared__ uint32_t s_list[RT_BLOCK / RT_WAVE][3 * RT_WAVE];
     __shared__ float4 s_box[64];  // objBox of the first 32 objects: the rays' object masks are computed from here (reach_mask_from)
-    const uint32_t nBox = sc.reachCount;
-    if (threadIdx.x < 2u * nBox) s_box[threadIdx.x] = sc.objBox[threadIdx.x];
+    const uint32_t nBox = CULL ? sc.reachCount : 0u;
+    if (CULL && threadIdx.x < 2u * nBox) s_box[threadIdx.x] = sc.maskBox[threadIdx.x];
     __syncthreads();
     const uint32_t wv = threadIdx.x / RT_WAVE;
     uint32_t* stack = s_stack + wv * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
@@ -1273,7 +1281,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
         uint32_t nRays = __popcll(mA);
         while (nRays) {
             __threadfence_block();  // the rays written by shade_path / init_path are read by other lanes of this wave
-            trace_wave<STACK, OVF, PIX, false, true>(sc, ps, ta, stack, ovf, ovfStride, list, nRays, wt);
+            trace_wave<STACK, OVF, PIX, false, true, CULL>(sc, ps, ta, stack, ovf, ovfStride, list, nRays, wt);
             __threadfence_block();  // ... and so are the hit records
             bool nowAlive = false, wantAux = false;
             uint32_t refRays = 0, nPaths = 0;
@@ -1282,7 +1290,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
                 fq = &kq->fp; sq = &kq->sc;
                 shade_path(*sq, ps, *fq, slot, nowAlive, wantAux, refRays, nPaths, false);
                 segTot++;
-                if (nowAlive && nBox) {
+                if (CULL && nowAlive && nBox) {
                     // the new rays' object masks (sphere_seed), here rather than inside shade_path: its registers are spilling already
                     float4 sd = ps.hit(RAY_MAIN)[slot];
                     sd.z = __uint_as_float(reach_mask_from(s_box, nBox, f4xyz(ps.rayO()[slot]), f4xyz(ps.rayD()[slot])));
