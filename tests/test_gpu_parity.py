@@ -420,3 +420,28 @@ def test_many_separate_identity_objects_of_different_materials(renderer):
     W, H = 128, 96
     pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3, bounceLimit=6)
     _check(*_render_both(renderer, s, pc, W, H))
+
+
+@pytest.mark.parametrize("config", ["cornell", "bunny", "dragon", "sponza", "sponza_dragons"])
+def test_every_bench_scene_is_identical_across_the_three_kernels(renderer, config):
+    """The BASELINE configs (full triangle counts) through k_trace (one ray per lane, no object skipping, no shared traversal
+    code), k_trace_pw and k_render_fused: same pixels, same counters. The oracle is too slow for these sizes; k_trace, which
+    the small-scene tests pin to the oracle, stands in for it."""
+    scene, _ = scenes.CONFIGS[config]()
+    r = renderer
+    r.upload_scene(scene)
+    W, H = 384, 216
+    cam = scenes.sponza_camera if config.startswith("sponza") else engine.push_constants
+    pc = cam(W, H, singleRender=1, sampleLimit=2)
+    out = []
+    for knobs in ({"pipeline": 0, "trace_variant": 0}, {"pipeline": 0, "trace_variant": 1}, {"pipeline": 1}):
+        for k, v in knobs.items():
+            r.set_tuning(k, v)
+        r.reset_counters()
+        img = r.render(pc, W, H)
+        c = r.counters()
+        out.append((img, {k: c[k] for k in ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments")}))
+    r.set_tuning("trace_variant", 1)
+    for img, cnt in out[1:]:
+        assert np.array_equal(img.view(np.uint32), out[0][0].view(np.uint32))
+        assert cnt == out[0][1]
