@@ -252,10 +252,9 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
     }
     RT_HIP(c, hipMemsetAsync(c->q.counts + 5, 0, 4, c->stream));
     // lanes at interior nodes that make the wave skip the vote: long rays (Sponza: 157 box tests per ray) want the interior step
-    // to wait for more lanes (40: -4 %), short rays (Cornell + model: 33..37) for fewer (16: -1 %); 24 until the scene is measured
-    const uint32_t fastLanes = c->fastLanesSet ? (uint32_t)c->fastLanes : (c->boxPerRay < 0.0 ? 24u : (c->boxPerRay >= (double)c->fusedBelowBoxTests ? 40u : 16u));
-    const bool shortRays = c->boxPerRay >= 0.0 && c->boxPerRay < (double)c->fusedBelowBoxTests;
-    const uint32_t wLeaf = (!c->wLeafSet && shortRays) ? 16u : (uint32_t)c->wLeafFused;  // short rays: 16 is 1-2 % better than 24
+    // to wait for more lanes (40: -4 %); 24 for short rays and until the scene is measured
+    const uint32_t fastLanes = c->fastLanesSet ? (uint32_t)c->fastLanes : (c->boxPerRay >= (double)c->fusedBelowBoxTests ? 40u : 24u);
+    const uint32_t wLeaf = (uint32_t)c->wLeafFused;
     unsigned long long* waveTimes = nullptr;
     if (c->phaseStats) {
         c->waveTimesCount = (size_t)blocks * (RT_BLOCK / RT_WAVE);
