@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="sponza", choices=["cornell", "bunny", "dragon", "sponza", "sponza_dragons"])
+    ap.add_argument("--scene", default="sponza", choices=["cornell", "bunny", "dragon", "sponza", "sponza_dragons", "sponza_dragons_flat"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step")

@@ -327,10 +327,22 @@ def cornell_dragon():
     return cornell_with_model("dragon.obj", DRAGON_TRIS, 4, seed=3)
 
 
-def sponza(dragons=0, ntris=SPONZA_TRIS, seed=1):
+def _bake_y(pos, nrm, position, scale, angle_deg):
+    """Vertices and normals of a mesh placed by T * Ry * S (uniform S), in world space."""
+    a = np.radians(angle_deg)
+    c, sn = np.cos(a), np.sin(a)
+    R = np.array([[c, 0, sn], [0, 1, 0], [-sn, 0, c]])      # glm::rotate about +y
+    p = pos.reshape(-1, 3).astype(np.float64) * scale @ R.T + np.asarray(position, np.float64)
+    n = nrm.reshape(-1, 3).astype(np.float64) @ R.T
+    return p.astype(np.float32).reshape(-1, 9), n.astype(np.float32).reshape(-1, 9)
+
+
+def sponza(dragons=0, ntris=SPONZA_TRIS, seed=1, flatten=False):
     """C4 (dragons=0) / C5 (dragons=16): Sponza with materials from sponza.mtl
     (albedo = Ka*Kd, textures not sampled: SURVEY F3), a Cornell-style emitter at
-    the rectangle NEE is hard-wired to (raytrace.comp:368-387), environment on."""
+    the rectangle NEE is hard-wired to (raytrace.comp:368-387), environment on.
+    flatten=True is C5's second variant: no instancing, every dragon is its own
+    mesh with its placement baked into the vertices and its own BVH."""
     s = engine.Scene()
     s._l.rt_scene_set_sphere  # noqa: B018  (ten zeroed spheres, as prepare_storage_buffers)
     for i in range(10):
@@ -355,16 +367,22 @@ def sponza(dragons=0, ntris=SPONZA_TRIS, seed=1):
     s.read_obj(os.path.join(engine.ASSET_DIR, "light2.obj"), engine.placement(position=(0, -1.5, 0), frontOnly=True), 3)
     if dragons:
         path = _asset("dragon.obj")
-        if not path:
+        if not path or flatten:
             pos, nrm = blob(DRAGON_TRIS, seed=3, radius=1.0, center=(0, -1.0, 0))
         for i in range(dragons):
             gx, gz = i % 4, i // 4
-            p = engine.placement(position=(-3.0 + 2.0 * gx, 0.3, -7.5 + 5.0 * gz), scale=0.8, rotation=(0, 22.5 * i, 0))
-            if path:
+            where = (-3.0 + 2.0 * gx, 0.3, -7.5 + 5.0 * gz)
+            p = engine.placement(position=where, scale=0.8, rotation=(0, 22.5 * i, 0))
+            if flatten:
+                fp, fn = _bake_y(pos, nrm, where, 0.8, 22.5 * i)
+                s.add_mesh(f"flat:dragon/{i}", fp, fn, engine.placement(), 4 if i % 2 else 0)
+            elif path:
                 s.read_obj(path, p, 4 if i % 2 else 0)
             else:
                 s.add_mesh("standin:dragon.obj", pos, nrm, p, 4 if i % 2 else 0)
-        label += f"+{dragons}x{'dragon.obj' if path else 'synthetic-%d-tris' % DRAGON_TRIS}"
+        label += f"+{dragons}x{'dragon.obj' if path and not flatten else 'synthetic-%d-tris' % DRAGON_TRIS}"
+        if flatten:
+            label += "-flattened"
     return s, label
 
 
@@ -383,4 +401,5 @@ CONFIGS = {
     "dragon": cornell_dragon,
     "sponza": lambda: sponza(0),
     "sponza_dragons": lambda: sponza(16),
+    "sponza_dragons_flat": lambda: sponza(16, flatten=True),
 }

@@ -422,7 +422,7 @@ def test_many_separate_identity_objects_of_different_materials(renderer):
     _check(*_render_both(renderer, s, pc, W, H))
 
 
-@pytest.mark.parametrize("config", ["cornell", "bunny", "dragon", "sponza", "sponza_dragons"])
+@pytest.mark.parametrize("config", ["cornell", "bunny", "dragon", "sponza", "sponza_dragons", "sponza_dragons_flat"])
 def test_every_bench_scene_is_identical_across_the_three_kernels(renderer, config):
     """The BASELINE configs (full triangle counts) through k_trace (one ray per lane, no object skipping, no shared traversal
     code), k_trace_pw and k_render_fused: same pixels, same counters. The oracle is too slow for these sizes; k_trace, which
