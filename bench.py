@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, default); gloo only to rehearse N ranks on ONE GPU (strips gathered through host memory)")
     ap.add_argument("--tune", default="", help="comma-separated rt_set_tuning knobs, e.g. blocks_per_cu=2,refill=8")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="send a one-rank job through the process group, gather and reductions too (RCCL smoke test on a one-GPU box)")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole frame alone and compares it with the gathered one")
     args = ap.parse_args()
 
@@ -65,7 +67,13 @@ def main():
     if rehearsal:
         local = 0  # every rank shares GPU 0; RCCL cannot run two ranks on one device
     torch.cuda.set_device(local)
-    if world > 1:
+    multi = world > 1 or args.force_collective
+    if multi:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -90,7 +98,7 @@ def main():
 
     # N > 1: the strip of step i is copied aside and gathered while step i+1 renders (the progressive blend keeps
     # its history in `strip`, so the renderer goes on in place); the gather's kernels fill the tail of the render.
-    sendbuf = torch.zeros_like(strip) if world > 1 else None
+    sendbuf = torch.zeros_like(strip) if multi else None
     pending = [False]
 
     def launch(i):
@@ -99,24 +107,24 @@ def main():
 
     def finish_previous():
         if pending[0]:
-            tiling.gather_frame(sendbuf.cpu() if rehearsal else sendbuf, frame, H, world, rank)
+            tiling.gather_frame(sendbuf.cpu() if rehearsal else sendbuf, frame, H, world, rank, force_collective=multi)
             pending[0] = False
 
     def step(i):
         launch(i)
-        if world > 1:
+        if multi:
             finish_previous()      # gather of step i-1 overlaps the render of step i
         r.sync()
-        if world > 1:
+        if multi:
             sendbuf.copy_(strip)
             torch.cuda.current_stream().synchronize()
             pending[0] = True
 
     def fence():
-        if world > 1:
+        if multi:
             finish_previous()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -137,7 +145,7 @@ def main():
     keys = ["boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments"]
     vec = torch.tensor([float(cnt[k]) for k in keys] + [dt, trace_ms, float(trace_launches)], dtype=torch.float64,
                        device=fdev)
-    if world > 1:
+    if multi:
         mx = vec.clone()
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -181,7 +189,7 @@ def main():
                 out["roofline"]["traffic_source"] = os.path.relpath(tfile, ROOT)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(scene, pc, W, H, args)
-        if args.check and world > 1:
+        if args.check and multi:
             # the same frames rendered by one process must equal the stitched strips bit for bit
             r.reset_counters()
             solo = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
@@ -193,7 +201,7 @@ def main():
             if not same:
                 raise SystemExit("tiled frame differs from the single-GPU frame")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

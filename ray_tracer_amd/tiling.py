@@ -20,14 +20,15 @@ def max_rows(height, world):
     return (height + world - 1) // world
 
 
-def gather_frame(strip, frame, height, world, rank, dst=0):
+def gather_frame(strip, frame, height, world, rank, dst=0, force_collective=False):
     """Gather per-rank strips [(rows_r), W, 4] into frame [H, W, 4] on `dst`.
 
     `strip` holds this rank's rows in order; strips are padded to a common
     row count for the collective. Works with nccl (= RCCL) device tensors
-    and with gloo CPU tensors.
+    and with gloo CPU tensors. `force_collective` sends a one-rank job through
+    the collective as well (the RCCL smoke test on a one-GPU box).
     """
-    if world == 1:
+    if world == 1 and not force_collective:
         if frame is not None:
             frame[:height].copy_(strip[:height])
         return frame

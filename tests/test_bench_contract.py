@@ -28,3 +28,18 @@ def test_bench_line_has_the_contract_fields():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+
+
+@pytest.mark.gpu
+def test_one_rank_job_through_rccl_stitches_the_single_process_frame():
+    """The N > 1 code path of bench.py (RCCL process group, strip gather overlapped with the next render, the
+    reductions of the counters, the closing barrier) on the one GPU of the box: a one-rank job forced through the
+    collectives must give the frame a plain single-process render gives (--check)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--spp", "2",
+                        "--scene", "cornell", "--width", "320", "--height", "181", "--cpu-seconds", "0",
+                        "--force-collective", "--check"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["check_tiled_equals_single"] is True
+    assert d["n_gpus"] == 1 and d["value"] > 0
