@@ -422,6 +422,33 @@ def test_many_separate_identity_objects_of_different_materials(renderer):
     _check(*_render_both(renderer, s, pc, W, H))
 
 
+def test_more_objects_than_the_object_mask_has_bits(renderer):
+    """Forty-five objects: the Cornell box's nine, then thirty-six small meshes alternating between rotated / scaled
+    placements (general transforms: entered only when the ray can reach their padded box), identity placements and
+    two-triangle cards whose BVH root is a leaf. The rays' object masks cover the first 32 objects only; the objects
+    beyond them, and the boundary itself, must be walked, counted and credited exactly as the reference's linear loop does."""
+    s = engine.Scene()
+    s.prepare_storage_buffers()
+    glow = s.add_material(engine.default_material(albedo=(0.9, 0.9, 0.3), emissionColor=(1.0, 0.9, 0.4), emissionStrength=2.0))
+    mats = [0, 1, 2, 4, 5, glow]
+    card = np.array([[[-0.06, 0, -0.06], [0.06, 0, -0.06], [0.06, 0, 0.06]], [[-0.06, 0, -0.06], [0.06, 0, 0.06], [-0.06, 0, 0.06]]], np.float32)
+    ncard = np.zeros_like(card); ncard[..., 1] = -1
+    for k in range(36):
+        where = (-0.8 + 0.32 * (k % 6), -0.85 + 0.3 * (k // 6), -0.7 + 0.25 * (k % 5))
+        if k % 3 == 0:      # general transform, interior root
+            pos, nrm = scenes.blob(96 + 8 * k, seed=40 + k, radius=1.0)
+            s.add_mesh(f"g{k}", pos, nrm, engine.placement(position=where, scale=(0.09, 0.12, 0.07), rotation=(10 * k, 25 * k, 5 * k)), mats[k % 6])
+        elif k % 3 == 1:    # identity, interior root
+            pos, nrm = scenes.blob(64 + 6 * k, seed=40 + k, radius=0.09, center=where)
+            s.add_mesh(f"i{k}", pos, nrm, engine.placement(), mats[k % 6])
+        else:               # general transform, root is a leaf
+            s.add_mesh(f"c{k}", card, ncard, engine.placement(position=where, rotation=(35 * k, 0, 20 * k)), mats[k % 6])
+    assert s.counts()["objects"] == 45
+    W, H = 128, 96
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3, bounceLimit=6)
+    _check(*_render_both(renderer, s, pc, W, H))
+
+
 @pytest.mark.parametrize("config", ["cornell", "bunny", "dragon", "sponza", "sponza_dragons", "sponza_dragons_flat"])
 def test_every_bench_scene_is_identical_across_the_three_kernels(renderer, config):
     """The BASELINE configs (full triangle counts) through k_trace (one ray per lane, no object skipping, no shared traversal
