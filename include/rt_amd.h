@@ -305,6 +305,9 @@ int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
  *   "scatter"        fused pipeline: a block is made of chunks of this many consecutive slots taken from all
  *                    over the tile (0 = a block is neighbouring pixels; -1, default = 4 when a wave gets at
  *                    most two blocks, else 0)
+ *   "pixel_refill"   fused pipeline: free lanes at which a wave resolves its finished pixels and reserves new ones,
+ *                    1..64 (64 = a block at a time); 0 (default) = 8 when the scene's rays are long (the measure the
+ *                    pipeline choice uses), else 64
  *   "batch_pixels"   fused pipeline: pixels per wave-private block, 1..64; 0 (default) = chosen per
  *                    launch so the blocks divide evenly over the resident waves ("batch_fixed" is
  *                    the fixed cost per block, in pixel units, that the chooser assumes) */

@@ -90,6 +90,7 @@ struct rt_ctx {
     bool cull = false;      // kernels with the object-skipping code (CULL) for this scene
     int maskIdentity = 0;   // identity-transform objects in the rays' object masks too (rt_update_objects reads it)
     int scatter = -1;       // fused pipeline: blocks made of chunks of this many slots from all over the tile; 0 = neighbouring pixels; -1 = auto
+    int pixelRefill = 0;    // fused pipeline: free lanes at which a wave reserves new pixels (64 = a block at a time, 0 = by ray length)
     int batchPixels = 0;    // fused pipeline: pixels per wave-private block (0 = chosen per launch)
     int batchFixed = 80;    // ... and the fixed part of a block's cost in the chooser, in pixel units
     int lastBatchPixels = 0;
@@ -214,9 +215,9 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
 // same number of blocks shortens that critical path. Measured block time ~ (80 + pixels) (drain of the
 // longest ray and the shading step do not shrink with the block); beyond two blocks per wave the
 // dynamic hand-out evens the waves out by itself and whole 8x8 blocks are best.
-uint32_t fused_batch_pixels(const rt_ctx* c, uint32_t nPixels, uint32_t waves) {
+uint32_t fused_batch_pixels(const rt_ctx* c, uint32_t nPixels, uint32_t waves, uint32_t evenBelow) {
     if (c->batchPixels > 0) return (uint32_t)std::min(c->batchPixels, (int)RT_WAVE);
-    if (((uint64_t)nPixels + RT_WAVE - 1) / RT_WAVE > 2ull * waves) return RT_WAVE;
+    if (((uint64_t)nPixels + RT_WAVE - 1) / RT_WAVE > (uint64_t)evenBelow * waves) return RT_WAVE;
     uint32_t best = RT_WAVE;
     uint64_t bestCost = ~0ull;
     for (uint32_t b = RT_WAVE; b >= 16; b--) {
@@ -235,12 +236,18 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_render_fused<STACK, OVF, false, CULL>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
     }
     const uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
-    uint32_t batchPixels = fused_batch_pixels(c, fp.nPixels, resident * (RT_BLOCK / RT_WAVE));
-    // With one or two blocks per wave the tile is done when the most expensive block is: blocks made of 4-slot chunks from
+    // Pixels are replaced as they finish when rays are long (Sponza -7 %, its 1/2 and 1/4 tiles -8 % and -11 %: the wave no
+    // longer drains to its slowest pixel once per block); with short rays a block at a time is 4-7 % faster (Cornell,
+    // + bunny, + dragon), and so it is until the scene is measured
+    const uint32_t pixelRefill = c->pixelRefill > 0 ? (uint32_t)c->pixelRefill : (c->boxPerRay >= (double)c->fusedBelowBoxTests ? 8u : (uint32_t)RT_WAVE);
+    // a wave that replaces its pixels one by one evens out by itself as soon as there is more than one block per wave
+    const uint32_t evenBelow = pixelRefill < RT_WAVE ? 1u : 2u;
+    uint32_t batchPixels = fused_batch_pixels(c, fp.nPixels, resident * (RT_BLOCK / RT_WAVE), evenBelow);
+    // With one or two blocks per wave (one, when pixels are replaced as they finish) the tile is done when the most expensive block is: blocks made of 4-slot chunks from
     // all over the tile cost about the same (-6 % on a 1/8-height 1080p tile); with more blocks per wave the dynamic
     // hand-out balances by itself and neighbouring pixels (shared cache lines, coherent rays) are 3-8 % faster.
     const uint32_t wavesResident = resident * (RT_BLOCK / RT_WAVE);
-    const uint32_t g = c->scatter >= 0 ? (uint32_t)c->scatter : ((((uint64_t)fp.nPixels + RT_WAVE - 1) / RT_WAVE <= 2ull * wavesResident) ? 4u : 0u);
+    const uint32_t g = c->scatter >= 0 ? (uint32_t)c->scatter : ((((uint64_t)fp.nPixels + RT_WAVE - 1) / RT_WAVE <= (uint64_t)evenBelow * wavesResident) ? 4u : 0u);
     if (g) batchPixels = std::min((uint32_t)RT_WAVE, (batchPixels + g - 1) / g * g);
     const uint32_t nBatches = g ? ((fp.nPixels + g - 1) / g + batchPixels / g - 1) / (batchPixels / g) : (fp.nPixels + batchPixels - 1) / batchPixels;
     const uint32_t blocks = std::max(1u, std::min((nBatches + (RT_BLOCK / RT_WAVE) - 1) / (RT_BLOCK / RT_WAVE), resident));
@@ -262,7 +269,7 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
         if (rc) return rc;
         waveTimes = (unsigned long long*)c->waveTimeBuf.p;
     }
-    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, wLeaf, fastLanes, batchPixels, g, (uint32_t)c->fastShare, waveTimes};
+    FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, wLeaf, fastLanes, batchPixels, g, (uint32_t)c->fastShare, waveTimes, pixelRefill};
     c->lastBatchPixels = (int)batchPixels;
     const FusedKernArgs ka{c->sc, c->ps, fp, fa};
     if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
@@ -1002,6 +1009,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "mask_identity") { c->maskIdentity = value != 0; }
     else if (k == "fast_share") { if (value < 0 || value > 16) return c->fail("fast_share: 0..16"); c->fastShare = value; }
     else if (k == "scatter") { if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return c->fail("scatter: -1 (auto), 0, 1, 2, 4, 8 or 16"); c->scatter = value; }
+    else if (k == "pixel_refill") { if (value < 0 || value > (int)RT_WAVE) return c->fail("pixel_refill must be 0 (by ray length) .. 64"); c->pixelRefill = value; }
     else if (k == "batch_pixels") { if (value < 0 || value > (int)RT_WAVE) return c->fail("batch_pixels must be 0 (auto) .. 64"); c->batchPixels = value; }
     else if (k == "batch_fixed") { if (value < 0 || value > 4096) return c->fail("batch_fixed out of range"); c->batchFixed = value; }
     else if (k == "phase_stats") { c->phaseStats = value != 0; }

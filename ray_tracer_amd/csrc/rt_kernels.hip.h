@@ -1203,7 +1203,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathState ps, FrameParams 
 // the multi-kernel pipeline does (measured: 44 % of its full-frame efficiency on a 1/8-height tile).
 // Pixels are identical by construction: the per-pixel code is the same device functions.
 struct FusedArgs {
-    uint32_t* batchHead;   // zeroed before the launch
+    uint32_t* batchHead;   // zeroed before the launch; counts reserved pixel slots
     float4* rgba;
     DevCounters* counters;
     uint32_t* overflow;    // OVF only
@@ -1212,6 +1212,7 @@ struct FusedArgs {
     uint32_t scatter;      // g > 0: a block is made of chunks of g consecutive slots taken nBatches chunks apart
     uint32_t fastShare;
     unsigned long long* waveTimes;  // phase_stats only: wall_clock64() at the start and the end of every wave
+    uint32_t pixelRefill;  // free lanes that make the wave reserve new pixels (>= batchPixels: only when all are free)
 };
 
 // The kernel-argument segment as memory the compiler knows nothing about: loads through the returned pointer
@@ -1257,75 +1258,99 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
     const uint32_t nBatches = fa.scatter ? ((fp.nPixels + fa.scatter - 1) / fa.scatter + fa.batchPixels / fa.scatter - 1) / (fa.batchPixels / fa.scatter)
                                          : (fp.nPixels + fa.batchPixels - 1) / fa.batchPixels;
 
+    // A lane keeps a pixel until all its samples are done, then resolves it and takes the next one: when `pixelRefill`
+    // of the wave's lanes are free (or all of them), the wave reserves that many slots with one atomic. The wave stays
+    // populated until the tile runs out, instead of draining to its slowest pixel once per block.
+    const uint32_t total = fa.scatter ? nBatches * fa.batchPixels : fp.nPixels;
+    const uint32_t refillAt = min(max(fa.pixelRefill, 1u), fa.batchPixels);
+    uint32_t slot = 0;
+    bool valid = false, alive = false, wantAux = false, exhausted = false;
     for (;;) {
-        uint32_t batch = 0;
-        if (lane_id() == 0) batch = atomicAdd(fa.batchHead, 1u);
-        batch = __shfl(batch, 0, RT_WAVE);
-        if (batch >= nBatches) break;
-        // scatter: a block's pixels are spread over the whole tile (lane * nBatches + batch) instead of being
-        // neighbours, so that all blocks cost about the same when every wave gets just one of them
-        // (chunks of `scatter` consecutive slots, so that the path state is still read in whole 64/128-byte pieces)
-        const uint32_t slot = fa.scatter ? ((lane_id() / fa.scatter) * nBatches + batch) * fa.scatter + (lane_id() % fa.scatter)
-                                         : batch * fa.batchPixels + lane_id();
-        const bool valid = lane_id() < fa.batchPixels && slot < fp.nPixels;
-        // Frame constants and the shading tables are re-read from the kernel-argument segment where they are used
-        // (the asm makes the pointers opaque, so the loads cannot be hoisted): held across the traversal loop they
-        // cost ~60 scalar registers of a kernel that has none to spare.
-        const FusedKernArgs* kq = opaque_kernarg<FusedKernArgs>();
-        const FrameParams* fq = &kq->fp;
-        const DevScene* sq = &kq->sc;
-        if (valid) init_path(*sq, ps, *fq, slot);
-        bool alive = valid && fp.samples > 0;
-        unsigned long long mA = __ballot(alive);
-        if (alive) list[lanes_below(mA)] = slot << 2;
-        uint32_t nRays = __popcll(mA);
-        while (nRays) {
-            __threadfence_block();  // the rays written by shade_path / init_path are read by other lanes of this wave
-            trace_wave<STACK, OVF, PIX, false, true, CULL>(sc, ps, ta, stack, ovf, ovfStride, list, nRays, wt);
-            __threadfence_block();  // ... and so are the hit records
-            bool nowAlive = false, wantAux = false;
+        const bool mine = lane_id() < fa.batchPixels && !alive;
+        const unsigned long long mF = __ballot(mine);
+        const uint32_t take = __popcll(mF);
+        if (!exhausted && take >= refillAt) {
+            uint32_t base = 0;
+            if (lane_id() == 0) base = atomicAdd(fa.batchHead, take);
+            base = __shfl(base, 0, RT_WAVE);
+            if (base >= total) exhausted = true;
+            else if (mine) {
+                // Frame constants and the shading tables are re-read from the kernel-argument segment where they are used
+                // (the asm makes the pointers opaque, so the loads cannot be hoisted): held across the traversal loop they
+                // cost ~60 scalar registers of a kernel that has none to spare.
+                const FusedKernArgs* kq = opaque_kernarg<FusedKernArgs>();
+                const FrameParams* fq = &kq->fp;
+                const DevScene* sq = &kq->sc;
+                if (valid) resolve_pixel(ps, *fq, fa.rgba, slot);
+                const uint32_t a = base + lanes_below(mF);
+                uint32_t ns = a;
+                if (fa.scatter) {
+                    // a block's pixels are spread over the whole tile (chunks of `scatter` consecutive slots, nBatches chunks
+                    // apart), so that all blocks cost about the same when every wave gets just one of them
+                    const uint32_t ch = a / fa.scatter, perBlock = fa.batchPixels / fa.scatter;
+                    ns = ((ch % perBlock) * nBatches + ch / perBlock) * fa.scatter + a % fa.scatter;
+                }
+                valid = a < total && ns < fp.nPixels;
+                slot = ns;
+                wantAux = false;
+                if (valid) {
+                    init_path(*sq, ps, *fq, slot);
+                    alive = fp.samples > 0;
+                }
+            }
+        }
+        const unsigned long long mA = __ballot(alive);
+        if (mA == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        const unsigned long long mX = __ballot(alive && wantAux);
+        const uint32_t nA = __popcll(mA), nX = __popcll(mX);
+        if (alive) {
+            list[lanes_below(mA)] = (slot << 2) | RAY_MAIN;
+            if (wantAux) {
+                const uint32_t ra = lanes_below(mX);
+                list[nA + ra] = (slot << 2) | RAY_NEE;
+                list[nA + nX + ra] = (slot << 2) | RAY_PROBE;
+            }
+        }
+        const uint32_t nRays = nA + 2u * nX;
+        __threadfence_block();  // the rays written by shade_path / init_path are read by other lanes of this wave
+        trace_wave<STACK, OVF, PIX, false, true, CULL>(sc, ps, ta, stack, ovf, ovfStride, list, nRays, wt);
+        __threadfence_block();  // ... and so are the hit records
+        if (alive) {
+            bool nowAlive = false;
             uint32_t refRays = 0, nPaths = 0;
-            if (alive) {
-                kq = opaque_kernarg<FusedKernArgs>();
-                fq = &kq->fp; sq = &kq->sc;
-                shade_path(*sq, ps, *fq, slot, nowAlive, wantAux, refRays, nPaths, false);
-                segTot++;
-                if (CULL && nowAlive && nBox) {
-                    // the new rays' object masks (sphere_seed), here rather than inside shade_path: its registers are spilling already
-                    float4 sd = ps.hit(RAY_MAIN)[slot];
-                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, f4xyz(ps.rayO()[slot]), f4xyz(ps.rayD()[slot])));
-                    ps.hit(RAY_MAIN)[slot] = sd;
-                    if (wantAux) {
-                        const rt_vec3 ao = f4xyz(ps.auxO()[slot]);
-                        sd = ps.hit(RAY_NEE)[slot];
-                        sd.z = __uint_as_float(reach_mask_from(s_box, nBox, ao, f4xyz(ps.auxDL()[slot])));
-                        ps.hit(RAY_NEE)[slot] = sd;
-                        sd = ps.hit(RAY_PROBE)[slot];
-                        sd.z = __uint_as_float(reach_mask_from(s_box, nBox, ao, f4xyz(ps.auxDC()[slot])));
-                        ps.hit(RAY_PROBE)[slot] = sd;
-                    }
+            const FusedKernArgs* kq = opaque_kernarg<FusedKernArgs>();
+            const FrameParams* fq = &kq->fp;
+            const DevScene* sq = &kq->sc;
+            wantAux = false;
+            shade_path(*sq, ps, *fq, slot, nowAlive, wantAux, refRays, nPaths, false);
+            segTot++;
+            if (CULL && nowAlive && nBox) {
+                // the new rays' object masks (sphere_seed), here rather than inside shade_path: its registers are spilling already
+                float4 sd = ps.hit(RAY_MAIN)[slot];
+                sd.z = __uint_as_float(reach_mask_from(s_box, nBox, f4xyz(ps.rayO()[slot]), f4xyz(ps.rayD()[slot])));
+                ps.hit(RAY_MAIN)[slot] = sd;
+                if (wantAux) {
+                    const rt_vec3 ao = f4xyz(ps.auxO()[slot]);
+                    sd = ps.hit(RAY_NEE)[slot];
+                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, ao, f4xyz(ps.auxDL()[slot])));
+                    ps.hit(RAY_NEE)[slot] = sd;
+                    sd = ps.hit(RAY_PROBE)[slot];
+                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, ao, f4xyz(ps.auxDC()[slot])));
+                    ps.hit(RAY_PROBE)[slot] = sd;
                 }
             }
             alive = nowAlive;
+            wantAux = wantAux && nowAlive;
             refTot += refRays;
             pathTot += nPaths;
-            mA = __ballot(alive);
-            const unsigned long long mX = __ballot(alive && wantAux);
-            const uint32_t nA = __popcll(mA), nX = __popcll(mX);
-            if (alive) {
-                list[lanes_below(mA)] = (slot << 2) | RAY_MAIN;
-                if (wantAux) {
-                    const uint32_t ra = lanes_below(mX);
-                    list[nA + ra] = (slot << 2) | RAY_NEE;
-                    list[nA + nX + ra] = (slot << 2) | RAY_PROBE;
-                }
-            }
-            nRays = nA + 2u * nX;
         }
-        __threadfence_block();
-        kq = opaque_kernarg<FusedKernArgs>();
-        fq = &kq->fp;
-        if (valid) resolve_pixel(ps, *fq, fa.rgba, slot);
+    }
+    if (valid) {  // the pixels that finished after the tile ran out
+        const FusedKernArgs* kq = opaque_kernarg<FusedKernArgs>();
+        resolve_pixel(ps, kq->fp, fa.rgba, slot);
     }
 
     if (fa.waveTimes && lane_id() == 0) {  // phase_stats: when did this wave run out of blocks?

@@ -18,13 +18,16 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4  # the north_star tolerance
 
 
-@pytest.fixture(params=[0, 1], ids=["multikernel", "fused"], autouse=True)
+@pytest.fixture(params=[(0, 0), (1, 64), (1, 8)], ids=["multikernel", "fused", "fused-refill"], autouse=True)
 def pipeline(request, renderer):
     """Every test runs on both pipelines: 0 = k_raygen / k_trace_pw / k_shade / k_resolve launched per round,
-    1 = k_render_fused (each wave runs the same stages on its own 8x8 pixel blocks)."""
-    renderer.set_tuning("pipeline", request.param)
-    yield request.param
+    1 = k_render_fused (each wave runs the same stages on its own pixels) — a block of pixels at a time (what it does
+    for scenes with short rays) and with finished pixels replaced as soon as eight lanes are free (long rays)."""
+    renderer.set_tuning("pipeline", request.param[0])
+    renderer.set_tuning("pixel_refill", request.param[1])
+    yield request.param[0]
     renderer.set_tuning("pipeline", -1)
+    renderer.set_tuning("pixel_refill", 0)
 
 
 def _render_both(r, scene, pc, W, H, **tile):
