@@ -314,6 +314,10 @@ int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
 int  rt_set_tuning(rt_ctx* ctx, const char* key, int value);
 /* pipeline the last rt_render used (0 or 1) */
 int  rt_last_pipeline(const rt_ctx* ctx);
+/* box tests per executed ray of the uploaded scene as this context measured them (the figure the launch parameters
+ * follow); < 0 while unknown. Measured from the counters of earlier dispatches, or — before the first dispatch of
+ * >= 8 M pixel-samples of a scene — by a probe dispatch of eight rows at one sample ("probe", 0 turns it off). */
+double rt_ray_cost(const rt_ctx* ctx);
 /* The reference's BVH builder on the GPU (csrc/bvh_build.hip.h): same nodes, same numbering, same triangle order as
  * the host builder of the scene half (a zero bound may differ in sign). Blocking. `seconds` (optional) = device time. */
 int  rt_bvh_build(rt_ctx* ctx, const TrianglePoint* points, uint32_t pointCount, Triangle* triangles, float* centroids,

@@ -137,6 +137,7 @@ SYMBOLS = {
     "rt_get_trace_time_ms": (C.c_int, [_vp, _P(C.c_double), _P(C.c_uint64)]),
     "rt_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "rt_last_pipeline": (C.c_int, [_vp]),
+    "rt_ray_cost": (C.c_double, [_vp]),
     "rt_bvh_build": (C.c_int, [_vp, _P(TrianglePoint), C.c_uint32, _P(Triangle), _P(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, _P(BVHNode), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
     "rt_bvh_hook": (C.c_int, [_vp, _P(TrianglePoint), C.c_uint32, _P(Triangle), _P(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, _P(BVHNode), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
     "rt_bvh_last_build_ms": (C.c_double, [_vp]),

@@ -94,6 +94,9 @@ struct rt_ctx {
     int batchPixels = 0;    // fused pipeline: pixels per wave-private block (0 = chosen per launch)
     int batchFixed = 80;    // ... and the fixed part of a block's cost in the chooser, in pixel units
     int lastBatchPixels = 0;
+    DevBuf probeBuf;        // framebuffer of the ray-cost probe
+    int probe = 1;          // measure an unknown scene with a small dispatch before its first big one
+    bool inProbe = false;
     DevBuf waveTimeBuf;     // phase_stats: per-wave start/end clocks of the last k_trace_pw launch
     size_t waveTimesCount = 0;
     bool pixStats = false;  // this dispatch needs per-pixel box/triangle counts (debug heat maps)
@@ -743,6 +746,40 @@ void request_ray_cost(rt_ctx* c) {
     if (hipEventRecord(c->snapEvent, c->stream) != hipSuccess) return;
     c->snapPending = true;
 }
+
+// The launch parameters of both pipelines follow the scene's measured box tests per ray, which the first dispatch of a
+// scene does not have — and a single-render job (the reference's singleRender mode: all samples in one dispatch) is
+// nothing but a first dispatch. Before a big one, eight rows of the same tile are rendered once with one sample per
+// pixel into a scratch image and the counters put back: a few ms, no trace in anything the caller can read.
+int probe_ray_cost(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t height, uint32_t row0, uint32_t rowStride, uint32_t nRows) {
+    const uint32_t rows = std::min(nRows, 8u), skip = nRows / rows;
+    PushConstants p = *pc;
+    p.rayTraceParams.singleRender = 1;
+    p.rayTraceParams.sampleLimit = 1;
+    p.rayTraceParams.progressive = 0;
+    p.rayTraceParams.debug = -1;
+    int rc = dev_alloc(c, c->probeBuf, (size_t)rows * width * sizeof(float4));
+    if (rc) return rc;
+    DevCounters before, after;
+    RT_HIP(c, hipMemcpyAsync(&before, c->counterBuf.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    const int pipeline = c->pipeline, lastPipeline = c->lastPipeline, lastBatch = c->lastBatchPixels;
+    const bool profiling = c->profiling, phaseStats = c->phaseStats;
+    const uint64_t launches = c->traceLaunchesTotal;
+    c->pipeline = 1; c->profiling = false; c->phaseStats = false; c->inProbe = true;
+    rc = rt_render(c, &p, width, height, row0 + (skip / 2u) * rowStride, rowStride * skip, rows, (float*)c->probeBuf.p);
+    c->pipeline = pipeline; c->profiling = profiling; c->phaseStats = phaseStats; c->inProbe = false;
+    c->lastPipeline = lastPipeline; c->lastBatchPixels = lastBatch; c->traceLaunchesTotal = launches;
+    if (rc) return rc;
+    RT_HIP(c, hipMemcpyAsync(&after, c->counterBuf.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpyAsync(c->counterBuf.p, &before, sizeof(DevCounters), hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->snapPending = false;  // the probe's own snapshot request: its copy has arrived, and it is not wanted
+    if (after.raysTraced > before.raysTraced + 1000ull)
+        c->boxPerRay = (double)(after.boxTests - before.boxTests) / (double)(after.raysTraced - before.raysTraced);
+    return 0;
+}
 }  // namespace
 
 extern "C" {
@@ -811,6 +848,12 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     // Both pipelines give the same bits; which one is faster depends on how much a wave has to do per pixel. Small tiles
     // and scenes with short rays (few box tests per ray, measured on this context's earlier dispatches) go to the fused one.
     poll_ray_cost(c);
+    if (c->boxPerRay < 0.0 && c->probe && !c->inProbe && (uint64_t)nPixels * fp.samples >= 8000000ull && td.debug < 0) {
+        c->sc = saved;
+        if ((rc = probe_ray_cost(c, pc, width, height, row0, rowStride, nRows))) return rc;
+        c->sc = sc;
+        c->pixStats = false;
+    }
     const bool shortRays = c->boxPerRay >= 0.0 && c->boxPerRay < (double)c->fusedBelowBoxTests;
     // the longer the rays, the earlier the global queue of the multi-kernel pipeline pays: Sponza (157 box tests per ray)
     // switches near 2.8 M pixels, Sponza + 16 dragons (213) near 1 M
@@ -994,6 +1037,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     if (!c || !key) return -1;
     std::string k(key);
     if (k == "pipeline") { if (value < -1 || value > 1) return c->fail("pipeline: -1 (auto), 0 or 1"); c->pipeline = value; }
+    else if (k == "probe") { c->probe = value ? 1 : 0; }
     else if (k == "fused_below_box_tests") { if (value < 0) return c->fail("fused_below_box_tests >= 0"); c->fusedBelowBoxTests = (uint32_t)value; }
     else if (k == "fused_below_pixels") { if (value < 0) return c->fail("fused_below_pixels >= 0"); c->fusedBelowPixels = (uint32_t)value; }
     else if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
@@ -1019,6 +1063,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
 }
 
 int rt_last_pipeline(const rt_ctx* c) { return c ? c->lastPipeline : -1; }
+double rt_ray_cost(const rt_ctx* c) { return c ? c->boxPerRay : -1.0; }
 
 // ---------------------------------------------------------------- GPU BVH build (bvh_build.hip.h)
 int rt_bvh_build(rt_ctx* c, const TrianglePoint* points, uint32_t pointCount, Triangle* triangles, float* centroids, uint32_t count,

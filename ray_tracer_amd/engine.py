@@ -321,6 +321,10 @@ class Renderer:
         """0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline."""
         return self._l.rt_last_pipeline(self._h)
 
+    def ray_cost(self):
+        """Measured box tests per executed ray of the uploaded scene (< 0: not measured yet)."""
+        return self._l.rt_ray_cost(self._h)
+
     def bvh_last_build_ms(self):
         return self._l.rt_bvh_last_build_ms(self._h)
 

@@ -352,6 +352,34 @@ def test_automatic_pipeline_choice(renderer):
     assert r.last_pipeline() == 1
 
 
+def test_ray_cost_probe_before_a_big_first_dispatch(renderer):
+    """A scene's first dispatch of >= 8 M pixel-samples is preceded by a probe (eight rows, one sample) that measures its
+    box tests per ray, so that a single-render job runs with the launch parameters of its ray length. The probe leaves no
+    trace: counters and pixels equal those of a context that never probed, and those of the oracle on sampled rows."""
+    r = renderer
+    r.set_tuning("pipeline", -1)
+    sp, _ = scenes.sponza(0, ntris=20000)
+    W, H = 1920, 1080
+    pc = scenes.sponza_camera(W, H, singleRender=1, sampleLimit=4)
+    out = []
+    for probe in (1, 0):
+        r.set_tuning("probe", probe)
+        r.upload_scene(sp)                      # a new scene: ray cost unknown
+        assert r.ray_cost() < 0
+        r.reset_counters()
+        img = r.render(pc, W, H)
+        out.append((img, r.counters(), r.ray_cost()))
+    r.set_tuning("probe", 1)
+    assert out[0][2] > 90, "measured before the dispatch (Sponza stand-in: long rays)"
+    assert out[1][2] < 0 or out[1][2] > 90      # without the probe: unknown until the counters come back
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    keys = ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments")
+    assert {k: out[0][1][k] for k in keys} == {k: out[1][1][k] for k in keys}
+    tile = dict(row0=50, rowStride=270, nRows=4)
+    ref, _ = pyoracle.render(sp, pc, W, H, **tile)
+    assert np.array_equal(out[0][0][50::270][:4].view(np.uint32), ref.view(np.uint32))
+
+
 def test_instances_nonuniform_transforms_emissive_mesh_and_ten_spheres(renderer):
     """One OBJ loaded four times (cached BVH, src/vk_engine.cpp:802-815) under rotated, non-uniformly scaled and mirrored
     placements, one instance emissive (a second light the hard-wired NEE knows nothing about), one dielectric; all ten
