@@ -1194,12 +1194,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathState ps, FrameParams 
 }
 
 // ---------------------------------------------------------------- k_render_fused (wave-private pipeline)
-// The same stages, run by each wave on its own 8x8 pixel block: init_path, then {trace_wave over the
-// block's ray list in LDS, shade_path, compaction of the next rays with __ballot ranks} until the
-// block's 64 pixels finished all their samples, then resolve_pixel; blocks of `batchPixels` <= 64 consecutive slots are handed out by one
-// atomic each. There is no device-wide barrier between the stages of different blocks, no
-// global ray queue and no per-round launch, so a small tile (one of 8 GPUs renders 1/8 of the
-// frame: ~340 k rays per round) does not wait for the slowest ray of the whole tile each round, as
+// The same stages, run by each wave on its own pixels: init_path, then {trace_wave over the wave's ray list
+// in LDS, shade_path, compaction of the next rays with __ballot ranks} until a pixel has finished all its
+// samples, then resolve_pixel. Slots are reserved with one atomic per hand-out: a block of `batchPixels` <= 64
+// consecutive slots when all lanes are free (pixelRefill = 64: a block at a time), or as many slots as there
+// are free lanes as soon as `pixelRefill` of them are free. There is no device-wide barrier between the stages
+// of different waves, no global ray queue and no per-round launch, so a small tile (one of 8 GPUs renders 1/8
+// of the frame: ~340 k rays per round) does not wait for the slowest ray of the whole tile each round, as
 // the multi-kernel pipeline does (measured: 44 % of its full-frame efficiency on a 1/8-height tile).
 // Pixels are identical by construction: the per-pixel code is the same device functions.
 struct FusedArgs {
