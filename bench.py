@@ -28,6 +28,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the pool's host driver only supports dmabuf IPC: without this RCCL's peer buffers fail with
+# hipIpcGetMemHandle: invalid argument (already exported on the GPU boxes; kept for any other launcher)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def main():
