@@ -190,6 +190,11 @@ def main():
             with open(tfile) as f:
                 out["roofline"]["traffic"] = json.load(f)["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = os.path.relpath(tfile, ROOT)
+        if world == 1:
+            # the nominal peak and a streaming copy measured on this very box (1 GiB, read + write), both quoted
+            out["roofline"]["measured_copy_gbps"] = r.copy_bandwidth_gbps(1 << 30, 5)
+            if achieved:
+                out["roofline"]["frac_of_measured_copy"] = achieved / out["roofline"]["measured_copy_gbps"]
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(scene, pc, W, H, args)
         if args.check and multi:
