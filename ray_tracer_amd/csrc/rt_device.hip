@@ -65,7 +65,7 @@ struct rt_ctx {
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
     int pipeline = -1;      // 0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline (k_render_fused), -1 = by tile size
     int lastPipeline = 0;   // what the last rt_render used
-    uint32_t fusedBelowPixels = 2800000;  // auto: tiles smaller than this use the fused pipeline (a 1080p frame does, 1440p and 4K do not)
+    uint32_t fusedBelowPixels = 6000000;  // auto: tiles smaller than this use the fused pipeline (1080p and 1440p frames do, 4K does not)
     uint32_t fusedBelowBoxTests = 90;     // auto: ... and so do scenes whose rays are short (box tests per ray, measured)
     // box tests per ray of this scene, from counter snapshots copied back asynchronously after each dispatch
     DevCounters* snap = nullptr;          // pinned
@@ -240,9 +240,12 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
     }
     const uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
     // Pixels are replaced as they finish when rays are long (Sponza -7 %, its 1/2 and 1/4 tiles -8 % and -11 %: the wave no
-    // longer drains to its slowest pixel once per block); with short rays a block at a time is 4-7 % faster (Cornell,
-    // + bunny, + dragon), and so it is until the scene is measured
-    const uint32_t pixelRefill = c->pixelRefill > 0 ? (uint32_t)c->pixelRefill : (c->boxPerRay >= (double)c->fusedBelowBoxTests ? 8u : (uint32_t)RT_WAVE);
+    // longer drains to its slowest pixel once per block) and when a wave gets fewer than five blocks (Cornell + bunny /
+    // + dragon, rank 0's rows of 2 GPUs -3 %, of 4 GPUs -13 %); with short rays and many blocks per wave a block at a
+    // time is 4-7 % faster (the full 1080p frame of Cornell, + bunny, + dragon)
+    const bool fewBlocks = ((uint64_t)fp.nPixels + RT_WAVE - 1) / RT_WAVE < 5ull * resident * (RT_BLOCK / RT_WAVE);
+    const uint32_t pixelRefill = c->pixelRefill > 0 ? (uint32_t)c->pixelRefill
+                               : ((c->boxPerRay >= (double)c->fusedBelowBoxTests || fewBlocks) ? 8u : (uint32_t)RT_WAVE);
     // a wave that replaces its pixels one by one evens out by itself as soon as there is more than one block per wave
     const uint32_t evenBelow = pixelRefill < RT_WAVE ? 1u : 2u;
     uint32_t batchPixels = fused_batch_pixels(c, fp.nPixels, resident * (RT_BLOCK / RT_WAVE), evenBelow);
@@ -856,9 +859,10 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     }
     const bool shortRays = c->boxPerRay >= 0.0 && c->boxPerRay < (double)c->fusedBelowBoxTests;
     // the longer the rays, the earlier the global queue of the multi-kernel pipeline pays: Sponza (157 box tests per ray)
-    // switches near 2.8 M pixels, Sponza + 16 dragons (213) near 1 M
+    // switches near 6 M pixels (1440p: fused 315 ms per 8 spp against 329; 4K: 700 against 686), Sponza + 16 dragons (213)
+    // near 2 M (1/8 of a 4K frame: 85 against 94; 1/4: 162 against 159)
     double sizeLimit = (double)c->fusedBelowPixels;
-    if (c->boxPerRay > 160.0) sizeLimit = std::max(800000.0, sizeLimit - (c->boxPerRay - 160.0) * 34000.0);
+    if (c->boxPerRay > 160.0) sizeLimit = std::max(800000.0, sizeLimit - (c->boxPerRay - 160.0) * 75000.0);
     c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (((double)nPixels < sizeLimit || shortRays) ? 1 : 0);
     if (c->lastPipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch
         rc = launch_fused(c, fp, fb);

@@ -342,14 +342,16 @@ def test_automatic_pipeline_choice(renderer):
     assert r.last_pipeline() == 1, "Cornell has ~10 box tests per ray"
     sp, _ = scenes.sponza(0, ntris=20000)
     r.upload_scene(sp)
+    W, H = 3840, 2160  # 8.3 M pixels
     pc = scenes.sponza_camera(W, H, singleRender=1, sampleLimit=1)
     r.render(pc, W, H)
-    assert r.last_pipeline() == 0, "not measured yet: by size"
+    assert r.last_pipeline() == 0, "by size"
     for _ in range(2):
         r.render(pc, W, H)
-    assert r.last_pipeline() == 0, "long rays (26 objects): the multi-kernel pipeline keeps big tiles"
-    r.render(scenes.sponza_camera(1920, 1080, singleRender=1, sampleLimit=1), 1920, 1080)
-    assert r.last_pipeline() == 1
+    assert r.last_pipeline() == 0, "long rays (26 objects): the multi-kernel pipeline keeps the biggest tiles"
+    for w, h in ((2560, 1440), (1920, 1080)):
+        r.render(scenes.sponza_camera(w, h, singleRender=1, sampleLimit=1), w, h)
+        assert r.last_pipeline() == 1
 
 
 def test_ray_cost_probe_before_a_big_first_dispatch(renderer):

@@ -1,0 +1,43 @@
+"""BASELINE.json's configurations on one MI355X at their quoted samples per pixel: Mrays/s in the reference's ray
+accounting, executed rays, samples/pixel/s and the algorithmic-bytes fraction of the 8 TB/s roofline, for the whole frame
+and for rank 0's interleaved rows of 2 / 4 / 8 GPUs (what one of N GPUs renders).  Markdown on stdout.
+usage: config_table.py [--quick]   (--quick: an eighth of the samples)"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ray_tracer_amd import engine, scenes  # noqa: E402
+
+quick = "--quick" in sys.argv
+CONFIGS = [  # name, scene, width, height, spp, spp per dispatch
+    ("C1 Cornell + 3 spheres", "cornell", 512, 512, 4, 4),
+    ("C2 Cornell + bunny", "bunny", 1920, 1080, 64, 64),
+    ("C3 Cornell + dragon (mirror)", "dragon", 1920, 1080, 256, 64),
+    ("C4 Sponza", "sponza", 1920, 1080, 1024, 64),
+    ("C5 Sponza + 16 dragons, 4K (128 of 4096 spp)", "sponza_dragons", 3840, 2160, 128, 16),
+]
+r = engine.Renderer(0)
+print("| config | GPUs (rows of rank 0) | spp | time | Mrays/s (reference accounting) | executed Mrays/s | spp/s | algorithmic GB/s | of 8 TB/s | pipeline |")
+print("|---|---|---|---|---|---|---|---|---|---|")
+for name, key, W, H, spp, per in CONFIGS:
+    scene, label = scenes.CONFIGS[key]()
+    cam = scenes.sponza_camera if key.startswith("sponza") else engine.push_constants
+    if quick:
+        spp = max(per if per < 8 else 8, spp // 8)
+        per = min(per, spp)
+    r.upload_scene(scene)
+    for world in (1, 2, 4, 8):
+        pc = cam(W, H, raysPerPixel=per, progressive=1, singleRender=0)
+        r.reset_counters()
+        r.sync()
+        t = time.perf_counter()
+        for i in range(spp // per):
+            pc.frameCount = i
+            r.render(pc, W, H, row0=0, rowStride=world, sync=False)
+        r.sync()
+        dt = time.perf_counter() - t
+        c = r.counters()
+        alg = 32.0 * c["boxTests"] + 36.0 * c["triTests"] + 100.0 * c["raysHit"]
+        print(f"| {name} ({label}) {W}x{H} | {world} | {spp} | {dt * 1e3:.1f} ms | {c['raysReference'] / dt / 1e6:.0f} | {c['raysTraced'] / dt / 1e6:.0f} | "
+              f"{spp / dt:.1f} | {alg / dt / 1e9:.0f} | {alg / dt / 8e12 * 100:.0f} % | {['multi-kernel', 'fused'][r.last_pipeline()]} |", flush=True)
