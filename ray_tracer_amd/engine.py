@@ -259,13 +259,14 @@ class Renderer:
             return None
         return self.read_rgba()
 
-    def run_compute(self, pc, width, height):
-        """Frame semantics of draw()/run_compute (src/vk_engine.cpp:1782,1812-1814)."""
+    def run_compute(self, pc, width, height, **tile):
+        """Frame semantics of draw()/run_compute (src/vk_engine.cpp:1782,1812-1814); `tile` = row0 / rowStride / nRows
+        of rt_render when the frame is split over several GPUs."""
         t = pc.rayTraceParams
         if self.totalSamples >= t.sampleLimit:
             return None
         pc.frameCount = self._frameNumber
-        img = self.render(pc, width, height)
+        img = self.render(pc, width, height, **tile)
         if t.singleRender:
             self.totalSamples = t.sampleLimit
         else:

@@ -10,8 +10,18 @@ draw() (src/vk_engine.cpp:1774-1815): dispatches run while
 totalSamples < sampleLimit; a single render is one dispatch of sampleLimit
 samples per pixel, otherwise each dispatch adds raysPerPixel samples and, when
 progressive, is blended into the fp32 frame with weight 1/(frame+1).
+
+Several GPUs of one node: launch one process per GPU,
+
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        -m ray_tracer_amd.render --scene sponza --single-render --sample-limit 1024 --out sponza.png
+
+rank r renders rows r, r+N, ... of the frame (the same pixels, bit for bit, as a
+single process), and one RCCL gather at the end brings the strips to rank 0,
+which writes the file.
 """
 import argparse
+import os
 import sys
 import time
 
@@ -30,7 +40,9 @@ def build_parser():
     ap.add_argument("--obj-position", type=float, nargs=3, default=(0.0, 0.53, 0.0))
     ap.add_argument("--width", type=int, default=1728)
     ap.add_argument("--height", type=int, default=1117)
-    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--device", type=int, default=0, help="GPU of a single-process run (one process per GPU uses LOCAL_RANK)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="several processes: nccl (= RCCL, one GPU per rank); gloo lets all ranks share --device (rehearsal on one GPU)")
     ap.add_argument("--out", help="PNG (8-bit sRGB) or .npy (fp32 RGBA) output file")
     # Ray Tracer Info panel
     ap.add_argument("--progressive", action="store_true")
@@ -89,33 +101,69 @@ def make_constants(args):
     return pc
 
 
+def srgb8(img):
+    """Display encoding of the fp32 frame, the one rt_read_rgba8_srgb applies."""
+    v = np.clip(np.nan_to_num(img, nan=0.0), 0.0, 1.0)
+    rgb = np.where(v[..., :3] <= 0.0031308, 12.92 * v[..., :3], 1.055 * np.power(v[..., :3], 1.0 / 2.4) - 0.055)
+    return (np.concatenate([rgb, v[..., 3:]], axis=-1) * 255.0 + 0.5).astype(np.uint8)
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    device = args.device
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from . import tiling
+        if args.backend == "nccl":
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
     scene, label = make_scene(args)
     pc = make_constants(args)
-    r = engine.Renderer(args.device)
+    r = engine.Renderer(device)
     r.upload_scene(scene)
     W, H = args.width, args.height
+    tile = dict(row0=rank, rowStride=world) if world > 1 else {}
     t0 = time.perf_counter()
     frames = 0
     img = None
     while True:
-        out = r.run_compute(pc, W, H)
+        out = r.run_compute(pc, W, H, **tile)
         if out is None:
             break
         img = out
         frames += 1
+    if world > 1 and img is not None:   # strips -> frame on rank 0
+        on = f"cuda:{device}" if args.backend == "nccl" else "cpu"
+        strip = torch.from_numpy(img).to(on)
+        frame = torch.zeros((H, W, 4), dtype=torch.float32, device=on) if rank == 0 else None
+        tiling.gather_frame(strip, frame, H, world, rank)
+        img = frame.cpu().numpy() if rank == 0 else None
     dt = time.perf_counter() - t0
     c = r.counters()
-    print(f"{label}: {W}x{H}, {r.totalSamples} spp in {frames} dispatch(es), {dt:.3f} s, "
-          f"{c['raysReference'] / dt / 1e6:.0f} Mrays/s (reference semantics), {c['raysTraced'] / dt / 1e6:.0f} M executed rays/s")
-    if args.out and img is not None:
-        if args.out.endswith(".npy"):
-            np.save(args.out, img)
-        else:
-            from PIL import Image
-            Image.fromarray(r.read_rgba8_srgb()[..., :3]).save(args.out)
-        print("wrote", args.out)
+    if world > 1:
+        tot = torch.tensor([float(c["raysReference"]), float(c["raysTraced"])], dtype=torch.float64,
+                           device=f"cuda:{device}" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tot)
+        c = {"raysReference": float(tot[0]), "raysTraced": float(tot[1])}
+    if rank == 0:
+        print(f"{label}: {W}x{H}, {r.totalSamples} spp in {frames} dispatch(es)" + (f" on {world} GPUs" if world > 1 else "") +
+              f", {dt:.3f} s, {c['raysReference'] / dt / 1e6:.0f} Mrays/s (reference semantics), {c['raysTraced'] / dt / 1e6:.0f} M executed rays/s")
+        if args.out and img is not None:
+            if args.out.endswith(".npy"):
+                np.save(args.out, img)
+            else:
+                from PIL import Image
+                Image.fromarray((srgb8(img) if world > 1 else r.read_rgba8_srgb())[..., :3]).save(args.out)
+            print("wrote", args.out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 
