@@ -455,6 +455,47 @@ def test_many_separate_identity_objects_of_different_materials(renderer):
     _check(*_render_both(renderer, s, pc, W, H))
 
 
+# RT_RANDOM_SEEDS=n widens the sweep (a soak run; the default keeps the suite short)
+@pytest.mark.parametrize("seed", list(range(1, 1 + int(__import__("os").environ.get("RT_RANDOM_SEEDS", "8")))))
+def test_random_scenes(renderer, seed):
+    """Seeded random scenes: the Cornell box around (seeds 3 and 6: nothing around), up to four blob meshes under random (also mirrored and
+    non-uniformly scaled) placements, random spheres, random materials (diffuse, mirror, dielectric, emissive, mixtures
+    the panels allow), random camera, environment on or off, random bounce limit — pixels and counters against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    s = engine.Scene()
+    if seed % 3:
+        s.prepare_storage_buffers()
+    else:
+        for m in (engine.default_material(), engine.default_material(albedo=(1, 0, 0)), engine.default_material(albedo=(0, 1, 0)),
+                  engine.default_material(albedo=(0, 0, 0), emissionColor=(1, 1, 1), emissionStrength=2.4),
+                  engine.default_material(reflectance=1.0), engine.default_material(ior=2.0)):
+            s.add_material(m)
+        for i in range(10):
+            s.set_sphere(i, (0, 0, 0), 0.0, 0)
+    mats = list(range(6))
+    for _ in range(int(rng.integers(1, 4))):
+        kind = rng.integers(0, 4)
+        kw = dict(albedo=tuple(rng.random(3)))
+        if kind == 1: kw.update(reflectance=float(rng.random() * 0.9 + 0.1))
+        if kind == 2: kw.update(ior=float(1.1 + rng.random() * 1.5))
+        if kind == 3: kw.update(emissionColor=tuple(rng.random(3)), emissionStrength=float(rng.random() * 4))
+        mats.append(s.add_material(engine.default_material(**kw)))
+    for k in range(int(rng.integers(1, 5))):
+        pos, nrm = scenes.blob(int(rng.integers(40, 900)), seed=int(rng.integers(1, 1000)), radius=1.0)
+        sc = rng.uniform(0.08, 0.35, 3) * rng.choice([-1.0, 1.0], 3, p=[0.15, 0.85])
+        pl = engine.placement(position=tuple(rng.uniform(-0.7, 0.7, 3)), scale=tuple(sc) if rng.random() < 0.6 else float(abs(sc[0])),
+                              rotation=tuple(rng.uniform(-180, 180, 3)) if rng.random() < 0.7 else (0, 0, 0))
+        s.add_mesh(f"r{seed}_{k}", pos, nrm, pl, int(rng.choice(mats)))
+    for i in range(int(rng.integers(0, 6))):
+        s.set_sphere(i, tuple(rng.uniform(-0.8, 0.8, 3)), float(rng.uniform(0.05, 0.35)), int(rng.choice(mats)))
+    W, H = 96, 72
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=int(rng.integers(1, 5)), bounceLimit=int(rng.integers(1, 11)),
+                               pos=(float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.8, 0.2)), float(rng.uniform(-3.8, -2.0))),
+                               cameraAngles=(float(rng.uniform(-10, 10)), float(rng.uniform(-15, 15)), float(rng.uniform(-5, 5))),
+                               fov=float(rng.uniform(35, 90)), environmentOn=bool(rng.random() < 0.5), frameCount=int(rng.integers(0, 4)))
+    _check(*_render_both(renderer, s, pc, W, H))
+
+
 def test_more_objects_than_the_object_mask_has_bits(renderer):
     """Forty-five objects: the Cornell box's nine, then thirty-six small meshes alternating between rotated / scaled
     placements (general transforms: entered only when the ray can reach their padded box), identity placements and
