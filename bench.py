@@ -28,9 +28,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# the pool's host driver only supports dmabuf IPC: without this RCCL's peer buffers fail with
-# hipIpcGetMemHandle: invalid argument (already exported on the GPU boxes; kept for any other launcher)
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # see ray_tracer_amd.tiling.prepare_rccl_env (set before torch loads RCCL)
+
+
+SCENE_NAMES = {"cornell": "Cornell", "bunny": "Cornell + bunny", "dragon": "Cornell + dragon", "sponza": "Sponza",
+               "sponza_dragons": "Sponza + 16 dragon instances", "sponza_dragons_flat": "Sponza + 16 dragons (flattened)"}
 
 
 def main():
@@ -62,8 +64,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not os.path.exists(ge.LIB):
-        ge.build()
+    ge.build()  # mtime check under a file lock: one rank compiles if anything is stale, the others wait for it
     from ray_tracer_amd import engine, scenes, tiling
 
     rehearsal = args.backend == "gloo"
@@ -80,6 +81,7 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
+            tiling.prepare_rccl_env()
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     W, H = args.width, args.height
@@ -161,7 +163,7 @@ def main():
         # per GPU: the kernel's algorithmic bytes per launch / its average launch duration
         achieved = (alg_bytes / max(sum_launches, 1.0)) / ((sum_trace_ms / max(sum_launches, 1.0)) * 1e-3) / 1e9 if sum_trace_ms > 0 else None
         out = {
-            "metric": "Mrays/s (reference-semantics closest-hit queries) at 1920x1080 Sponza",
+            "metric": f"Mrays/s (reference-semantics closest-hit queries) at {W}x{H} {SCENE_NAMES[args.scene]}",
             "value": tot["raysReference"] / dt / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -196,7 +198,18 @@ def main():
             if achieved:
                 out["roofline"]["frac_of_measured_copy"] = achieved / out["roofline"]["measured_copy_gbps"]
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(scene, pc, W, H, args)
+            out["cpu_baseline"], ref_rows, tile = cpu_baseline(scene, pc, W, H, args)
+            # the rows the oracle has just rendered are the rows of the bench frame at frameCount 0: render them on the
+            # GPU with the same constants and compare, bit for bit (the oracle is the checker here, never the product)
+            r.reset_counters()
+            pc.frameCount = 0
+            gpu_rows = r.render(pc, W, H, **tile)
+            same = bool(np.array_equal(gpu_rows.view(np.uint32), ref_rows.view(np.uint32)))
+            with np.errstate(all="ignore"):
+                rel = np.abs(gpu_rows - ref_rows) / np.maximum(np.abs(ref_rows), 1e-6)
+            out["parity_check"] = {"rows": tile["nRows"], "pixels": int(tile["nRows"] * W), "spp": args.spp, "equal": same,
+                                   "max_rel": float(np.nanmax(rel)) if rel.size else 0.0,
+                                   "against": "oracle (scalar restatement of raytrace.comp), same rows, frameCount 0"}
         if args.check and multi:
             # the same frames rendered by one process must equal the stitched strips bit for bit
             r.reset_counters()
@@ -209,6 +222,8 @@ def main():
             if not same:
                 raise SystemExit("tiled frame differs from the single-GPU frame")
         print(json.dumps(out), flush=True)
+        if out.get("parity_check", {}).get("equal") is False:
+            raise SystemExit("parity_check failed: the GPU rows differ from the oracle's")
     if multi:
         dist.barrier()
         dist.destroy_process_group()
@@ -228,12 +243,12 @@ def cpu_baseline(scene, pc, W, H, args):
     stride = max(1, H // n_rows)
     n_rows = min(n_rows, (H + stride - 1) // stride)
     t = time.perf_counter()
-    _, c = pyoracle.render(scene, pc, W, H, row0=0, rowStride=stride, nRows=n_rows, threads=threads)
+    rows, c = pyoracle.render(scene, pc, W, H, row0=0, rowStride=stride, nRows=n_rows, threads=threads)
     dt = time.perf_counter() - t
-    return {"value": c["raysReference"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+    return ({"value": c["raysReference"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{n_rows} of {H} rows (every {stride}th) of the same {W}x{H} frame at {args.spp} spp, "
                       f"{c['raysReference']} rays in {dt:.1f} s",
-            "unique_mrays_per_s": c["raysTraced"] / dt / 1e6}
+            "unique_mrays_per_s": c["raysTraced"] / dt / 1e6}, rows, dict(row0=0, rowStride=stride, nRows=n_rows))
 
 
 if __name__ == "__main__":

@@ -332,6 +332,9 @@ double rt_bvh_last_build_ms(const rt_ctx* ctx);
 /* device self-test of the deterministic-math build (must equal RT_SELFTEST_EXPECT) */
 int  rt_device_selftest(rt_ctx* ctx, uint32_t* bitsOut);
 uint32_t rt_host_selftest(void);
+/* Raw values of every GLSL built-in the shader uses (include/rt_probe.h), evaluated on the device: n inputs of 32
+ * floats, 64 floats out each. The tests compare them with independent numpy restatements of the GLSL 4.50 formulas. */
+int  rt_device_math_probe(rt_ctx* ctx, uint32_t n, const float* in, float* out);
 /* streaming-copy ceiling measured on this GPU (GB/s), quoted beside the 8 TB/s nominal */
 int  rt_measure_copy_bandwidth(rt_ctx* ctx, size_t bytes, int iters, double* gbpsOut);
 

@@ -65,6 +65,8 @@ def lib():
         l.oracle_math_probe.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float)]
         l.oracle_mat4_inverse.restype = None
         l.oracle_mat4_inverse.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        l.oracle_glsl_probe.restype = None
+        l.oracle_glsl_probe.argtypes = [C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.oracle_selftest.restype = C.c_uint32
         l.oracle_hardware_threads.restype = C.c_uint
         _lib = l
@@ -112,3 +114,12 @@ def math_probe(x, y):
     out = (C.c_float * 8)()
     lib().oracle_math_probe(float(x), float(y), out)
     return np.array(list(out), dtype=np.float32)
+
+
+def glsl_probe(inputs):
+    """include/rt_probe.h through the oracle's build: inputs [n, 32] float32 -> [n, 64] float32."""
+    x = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 32)
+    out = np.zeros((x.shape[0], 64), dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    lib().oracle_glsl_probe(x.shape[0], x.ctypes.data_as(fp), out.ctypes.data_as(fp))
+    return out

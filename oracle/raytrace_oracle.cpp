@@ -29,6 +29,7 @@
 
 #include "rt_amd.h"
 #include "rt_det_math.h"
+#include "rt_probe.h"
 #include "raytrace_oracle.h"
 
 #include <atomic>
@@ -561,6 +562,11 @@ void oracle_math_probe(float x, float y, float out[8]) {
 }
 
 void oracle_mat4_inverse(const float m[16], float out[16]) { rt_mat4_inverse(m, out); }
+
+// every GLSL built-in of SURVEY A12 on caller-supplied inputs (include/rt_probe.h): n x 32 floats in, n x 64 out
+void oracle_glsl_probe(uint32_t n, const float* in, float* out) {
+    for (uint32_t i = 0; i < n; i++) rt_math_probe(in + (size_t)i * 32, out + (size_t)i * 64);
+}
 
 uint32_t oracle_selftest(void) {
     volatile float in[7] = {1.0001220703125f, 0.9998779296875f, -1.f, 3.f, 1e-30f, 1e-10f, 2.f};

@@ -30,6 +30,8 @@ int oracle_trace_rays(const RtSceneArrays* scene, uint32_t sphereCount, uint32_t
 float oracle_random(uint32_t* state);
 void oracle_math_probe(float x, float y, float out[8]);
 void oracle_mat4_inverse(const float m[16], float out[16]);
+/* include/rt_probe.h on n inputs of 32 floats; 64 floats out each */
+void oracle_glsl_probe(uint32_t n, const float* in, float* out);
 uint32_t oracle_selftest(void);
 unsigned oracle_hardware_threads(void);
 

@@ -143,6 +143,7 @@ SYMBOLS = {
     "rt_bvh_last_build_ms": (C.c_double, [_vp]),
     "rt_device_selftest": (C.c_int, [_vp, _P(C.c_uint32)]),
     "rt_host_selftest": (C.c_uint32, []),
+    "rt_device_math_probe": (C.c_int, [_vp, C.c_uint32, _P(C.c_float), _P(C.c_float)]),
     "rt_measure_copy_bandwidth": (C.c_int, [_vp, C.c_size_t, C.c_int, _P(C.c_double)]),
     "rt_version": (C.c_char_p, []),
 }

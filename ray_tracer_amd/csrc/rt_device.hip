@@ -70,6 +70,7 @@ struct rt_ctx {
     // box tests per ray of this scene, from counter snapshots copied back asynchronously after each dispatch
     DevCounters* snap = nullptr;          // pinned
     hipEvent_t snapEvent = nullptr;
+    hipEvent_t pollEvent = nullptr;       // multi-kernel pipeline: the active-path count on its way back (never waited for)
     bool snapPending = false;
     unsigned long long snapBox = 0, snapRays = 0;  // counters at the previous snapshot
     double boxPerRay = -1.0;              // < 0: not measured yet
@@ -403,16 +404,18 @@ int rt_create(int device, rt_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return -4;
     rt_ctx* c = new rt_ctx();
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { delete c; return -5; }
+    if (hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) { c->ownStream = nullptr; rt_destroy(c); return -5; }
     c->stream = c->ownStream;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->numCUs = prop.multiProcessorCount;
     }
-    if (hipHostMalloc((void**)&c->hostCounts, 64, hipHostMallocDefault) != hipSuccess) { delete c; return -6; }
-    if (hipHostMalloc((void**)&c->snap, sizeof(DevCounters), hipHostMallocDefault) != hipSuccess) { delete c; return -6; }
-    if (hipEventCreateWithFlags(&c->snapEvent, hipEventDisableTiming) != hipSuccess) { delete c; return -6; }
-    if (dev_alloc(c, c->counterBuf, sizeof(DevCounters) + 128) != 0) { delete c; return -7; }
+    // every failure below goes through rt_destroy, which releases whatever exists by then (stream, pinned buffers, event)
+    if (hipHostMalloc((void**)&c->hostCounts, 64, hipHostMallocDefault) != hipSuccess) { c->hostCounts = nullptr; rt_destroy(c); return -6; }
+    if (hipHostMalloc((void**)&c->snap, sizeof(DevCounters), hipHostMallocDefault) != hipSuccess) { c->snap = nullptr; rt_destroy(c); return -6; }
+    if (hipEventCreateWithFlags(&c->snapEvent, hipEventDisableTiming) != hipSuccess) { c->snapEvent = nullptr; rt_destroy(c); return -6; }
+    if (hipEventCreateWithFlags(&c->pollEvent, hipEventDisableTiming) != hipSuccess) { c->pollEvent = nullptr; rt_destroy(c); return -6; }
+    if (dev_alloc(c, c->counterBuf, sizeof(DevCounters) + 128) != 0) { rt_destroy(c); return -7; }
     (void)hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 128, c->stream);
     (void)hipStreamSynchronize(c->stream);
     *out = c;
@@ -422,15 +425,16 @@ int rt_create(int device, rt_ctx** out) {
 void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->sceneBufs) dev_free(b);
     for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->stateBuf,
-                      &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf, &c->waveTimeBuf})
+                      &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf, &c->waveTimeBuf, &c->probeBuf})
         dev_free(*b);
     for (auto& e : c->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->hostCounts) (void)hipHostFree(c->hostCounts);
     if (c->snap) (void)hipHostFree(c->snap);
     if (c->snapEvent) (void)hipEventDestroy(c->snapEvent);
+    if (c->pollEvent) (void)hipEventDestroy(c->pollEvent);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -485,6 +489,7 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
     std::vector<uint4> meta(std::max(n, 1u));
     std::vector<float4> wbox((size_t)std::max(n, 1u) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
     uint32_t nGeneral = 0;
+    double minScale = 1e300;  // smallest size-and-position scale among the padded boxes
     for (uint32_t i = 0; i < n; i++) {
         float im[16];
         rt_mat4_inverse(o[i].transformMatrix, im);
@@ -524,6 +529,7 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
             if (finite) {
                 double pad = 1e-6;
                 for (int d = 0; d < 3; d++) pad = std::max(pad, 1e-3 * std::max(hi[d] - lo[d], std::max(std::fabs(lo[d]), std::fabs(hi[d]))));
+                minScale = std::min(minScale, pad * 1e3);
                 wbox[2 * (size_t)i] = make_float4((float)(lo[0] - pad), (float)(lo[1] - pad), (float)(lo[2] - pad), 0.f);
                 wbox[2 * (size_t)i + 1] = make_float4((float)(hi[0] + pad), (float)(hi[1] + pad), (float)(hi[2] + pad), 0.f);
                 boxOk = 6u;  // the rays' creators may rule the object out as well (bit 2)
@@ -558,6 +564,10 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
         }
     // one general-transform object among identity ones (Sponza's emitter) does not pay for either mechanism: measured +3 % and
     // +8..19 % on that scene; from two on they do (Cornell + model: -5..-13 %)
+    // The padding dominates the rounding of the world-space slab test and of the object-space ray only while the ray's
+    // origin is not much farther out than the objects are big: both errors grow like 6e-8 * |origin|. Rays
+    // that start beyond 1e3 object scales take the reference's own route through every object.
+    c->sc.cullOriginLimit = minScale < 1e300 ? (float)(minScale * 1e3) : 0.f;
     c->cull = nGeneral >= 2 || (c->maskIdentity && c->sc.reachCount);
     if (!c->cull) c->sc.reachCount = 0;
     if ((rc = upload(c, c->maskBoxBuf, maskBox.data(), maskBox.size() * sizeof(float4)))) return rc;
@@ -841,7 +851,11 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     sc.sphereCount = td.sphereCount;
     sc.objectCount = td.objectCount;
     if (sc.objectCount < c->sc.objectCount) sc.reachCount = 0;  // a dispatch with fewer objects than were uploaded: no masks
-    DevScene saved = c->sc;
+    // c->sc holds this dispatch's counts while the launches are built; whatever way the function is left, the uploaded scene comes back
+    struct SceneGuard {
+        rt_ctx* c; DevScene saved;
+        ~SceneGuard() { c->sc = saved; }
+    } guard{c, c->sc};
     c->sc = sc;
 
     const uint32_t blocksPix = (nPixels + RT_BLOCK - 1) / RT_BLOCK;
@@ -852,7 +866,7 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     // and scenes with short rays (few box tests per ray, measured on this context's earlier dispatches) go to the fused one.
     poll_ray_cost(c);
     if (c->boxPerRay < 0.0 && c->probe && !c->inProbe && (uint64_t)nPixels * fp.samples >= 8000000ull && td.debug < 0) {
-        c->sc = saved;
+        c->sc = guard.saved;
         if ((rc = probe_ray_cost(c, pc, width, height, row0, rowStride, nRows))) return rc;
         c->sc = sc;
         c->pixStats = false;
@@ -866,7 +880,6 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (((double)nPixels < sizeLimit || shortRays) ? 1 : 0);
     if (c->lastPipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch
         rc = launch_fused(c, fp, fb);
-        c->sc = saved;
         if (!rc) request_ray_cost(c);
         return rc;
     }
@@ -874,40 +887,43 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     RT_HIP(c, hipGetLastError());
 
     if (fp.samples > 0) {
-        // counts: [0],[1] active paths of buffer 0/1; [2],[3] rays of buffer 0/1
-        c->hostCounts[0] = nPixels; c->hostCounts[1] = 0; c->hostCounts[2] = nPixels; c->hostCounts[3] = 0; c->hostCounts[4] = 0;
-        RT_HIP(c, hipMemcpyAsync(counts, c->hostCounts, 20, hipMemcpyHostToDevice, c->stream));
-        RT_HIP(c, hipStreamSynchronize(c->stream));
+        // counts: [0],[1] active paths of buffer 0/1; [2],[3] rays of buffer 0/1; [4] the traversal's work counter
+        hipLaunchKernelGGL(k_init_counts, dim3(1), dim3(64), 0, c->stream, counts, nPixels);
 
-        uint32_t ubActive = nPixels;  // active paths never increase
+        // The whole dispatch is enqueued without waiting for the device (rt_amd.h: "asynchronous on the ctx stream"): every
+        // kernel reads its queue length from device memory and leaves at once when the queue is empty, so the loop may
+        // simply run to the most rounds a pixel can need, samples * (bounceLimit + 1). The active-path count is copied
+        // back now and then without ever being waited for; a copy that has arrived shrinks the grids of the launches still
+        // to be enqueued (active paths never increase, so a stale count is a valid upper bound) and ends the loop at zero.
+        uint32_t ubActive = nPixels;
         int cur = 0;
-        const int checkEvery = 8;
-        for (uint64_t it = 0;; it++) {
+        const uint64_t maxRounds = (uint64_t)fp.samples * ((uint64_t)fp.bounceLimit + 1);
+        bool pollPending = false;
+        for (uint64_t it = 0; it < maxRounds; it++) {
             const int nxt = cur ^ 1;
             hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, c->stream, counts + nxt, counts + 2 + nxt, counts + 4);
             TraceArgs ta{c->q.rays[cur], counts + 2 + cur, nullptr, nullptr, dc};
             uint64_t ubRays = std::min<uint64_t>((uint64_t)ubActive * 3, (uint64_t)nPixels * 3);
-            if ((rc = launch_trace(c, (uint32_t)ubRays, ta))) { c->sc = saved; return rc; }
+            if ((rc = launch_trace(c, (uint32_t)ubRays, ta))) return rc;
             ShadeArgs sa{c->q.active[cur], counts + cur, c->q.active[nxt], c->q.rays[nxt], counts + nxt, counts + 2 + nxt, dc};
             hipLaunchKernelGGL(k_shade, dim3((ubActive + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, sa, fp);
             cur = nxt;
-            if ((it + 1) % checkEvery == 0) {
-                RT_HIP(c, hipMemcpyAsync(c->hostCounts, counts + cur, 4, hipMemcpyDeviceToHost, c->stream));
-                RT_HIP(c, hipStreamSynchronize(c->stream));
-                if ((rc = harvest_events(c))) { c->sc = saved; return rc; }
-                ubActive = c->hostCounts[0];
+            if (pollPending && hipEventQuery(c->pollEvent) == hipSuccess) {
+                pollPending = false;
+                ubActive = std::min(ubActive, c->hostCounts[8]);
                 if (ubActive == 0) break;
             }
-            // hard stop: a pixel needs at most samples*(bounceLimit+1) rounds
-            if (it > (uint64_t)fp.samples * ((uint64_t)fp.bounceLimit + 1) + checkEvery) {
-                c->sc = saved;
-                return c->fail("internal: wavefront loop did not drain");
+            if (!pollPending && (it & 7u) == 7u) {
+                if (hipMemcpyAsync(c->hostCounts + 8, counts + cur, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                    hipEventRecord(c->pollEvent, c->stream) == hipSuccess)
+                    pollPending = true;
             }
         }
+        // (a copy still in flight when the loop ends is harmless: the stream orders it before the next dispatch's own
+        // copies, and the slot is only read after the event of the copy that filled it)
     }
     hipLaunchKernelGGL(k_resolve, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->ps, fp, fb);
     RT_HIP(c, hipGetLastError());
-    c->sc = saved;
     request_ray_cost(c);
     return 0;
 }
@@ -1227,6 +1243,23 @@ int rt_device_selftest(rt_ctx* c, uint32_t* bitsOut) {
     // bit 31 set: device and host disagree on some primitive
     *bitsOut = bits | (mismatches ? 0x80000000u : 0u);
     if (mismatches) return c->fail("device/host deterministic-math mismatch in " + std::to_string(mismatches) + " of 4096 probes");
+    return 0;
+}
+
+int rt_device_math_probe(rt_ctx* c, uint32_t n, const float* in, float* out) {
+    if (!c || !in || !out) return -1;
+    if (n == 0) return 0;
+    RT_HIP(c, hipSetDevice(c->device));
+    const size_t bi = (size_t)n * 32 * 4, bo = (size_t)n * 64 * 4;
+    int rc = dev_alloc(c, c->scratchBuf, bi + bo);
+    if (rc) return rc;
+    float* di = (float*)c->scratchBuf.p;
+    float* dout = di + (size_t)n * 32;
+    RT_HIP(c, hipMemcpyAsync(di, in, bi, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_math_probe, dim3((n + 63) / 64), dim3(64), 0, c->stream, di, dout, n);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipMemcpyAsync(out, dout, bo, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

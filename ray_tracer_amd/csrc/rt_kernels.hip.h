@@ -25,6 +25,7 @@
 
 #include "rt_amd.h"
 #include "rt_det_math.h"
+#include "rt_probe.h"
 
 #define RT_WAVE 64
 #define RT_BLOCK 256
@@ -69,6 +70,9 @@ struct DevScene {
     const float4* maskBox;   // reachCount x 2 float4: the objects a ray's creator tests for the ray's object mask (reach_mask_from)
     const uint2* objSkipCost; // 33 entries: {box tests, triangle tests} the reference spends on objects [0, i) when a ray misses them all
     uint32_t reachCount;     // entries of maskBox
+    float cullOriginLimit;   // rays that start farther out than this (max |origin component|) skip nothing: the padding of the world-space
+                             // boxes (1e-3 of an object's size and position) only dominates the slab tests' rounding, which grows with
+                             // |origin|, while the origin is within 1e3 object scales (rt_update_objects)
 };
 
 // ---------------------------------------------------------------- path state (SoA, one slot per pixel)
@@ -203,9 +207,12 @@ __device__ __forceinline__ bool ray_is_plain(rt_vec3 wo, rt_vec3 wd) {
 // on, and so does the traversal — by adding 2 to the count (trace_wave: fetch_next_meta). On the Sponza stand-in a ray
 // misses 16 of the 26 material groups' boxes on average. Same slab arithmetic as the traversal's (1/dir, box_intersect).
 // boxes: DevScene::maskBox, wherever the caller keeps it (k_render_fused: in LDS): n objects {lo.xyz, object index} {hi.xyz, -}
-__device__ __forceinline__ uint32_t reach_mask_from(const float4* boxes, uint32_t n, rt_vec3 ro, rt_vec3 rd) {
+__device__ __forceinline__ bool origin_within(rt_vec3 o, float limit) {
+    return rt_max(rt_max(rt_abs(o.x), rt_abs(o.y)), rt_abs(o.z)) <= limit;
+}
+__device__ __forceinline__ uint32_t reach_mask_from(const float4* boxes, uint32_t n, rt_vec3 ro, rt_vec3 rd, float originLimit) {
     uint32_t reach = 0xffffffffu;
-    if (n && ray_is_plain(ro, rd)) {
+    if (n && ray_is_plain(ro, rd) && origin_within(ro, originLimit)) {
         const rt_vec3 inv = rt_v3(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
         for (uint32_t k = 0; k < n; k++) {
             const float4 lo = boxes[2 * k], hi = boxes[2 * k + 1];
@@ -215,7 +222,7 @@ __device__ __forceinline__ uint32_t reach_mask_from(const float4* boxes, uint32_
     return reach;
 }
 __device__ __forceinline__ uint32_t reach_mask(const DevScene& sc, rt_vec3 ro, rt_vec3 rd) {
-    return reach_mask_from(sc.maskBox, sc.reachCount, ro, rd);
+    return reach_mask_from(sc.maskBox, sc.reachCount, ro, rd, sc.cullOriginLimit);
 }
 
 // withMask false: the caller adds the mask later (k_render_fused does, outside shade_path, where registers are not scarce)
@@ -637,7 +644,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     }
                     // a new ray whose first object has a general transform goes into it in this very step
                     bool general = cur == RT_CUR_SETUP || (cur == RT_CUR_INIT && sc.objectCount > 0u && !((nxFlags & 1u) && plain));
-                    if (CULL && general && plain) {
+                    if (CULL && general && plain && origin_within(wo, sc.cullOriginLimit)) {
                         // General-transform objects the ray cannot reach before its closest hit so far are not entered: in
                         // the reference such an object costs the two box tests on its root's children (its root leaf's triangle
                         // tests) and nothing else; that is what is counted. (objBox: padded world box; plain: finite ray.)
@@ -1331,15 +1338,15 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
             if (CULL && nowAlive && nBox) {
                 // the new rays' object masks (sphere_seed), here rather than inside shade_path: its registers are spilling already
                 float4 sd = ps.hit(RAY_MAIN)[slot];
-                sd.z = __uint_as_float(reach_mask_from(s_box, nBox, f4xyz(ps.rayO()[slot]), f4xyz(ps.rayD()[slot])));
+                sd.z = __uint_as_float(reach_mask_from(s_box, nBox, f4xyz(ps.rayO()[slot]), f4xyz(ps.rayD()[slot]), sc.cullOriginLimit));
                 ps.hit(RAY_MAIN)[slot] = sd;
                 if (wantAux) {
                     const rt_vec3 ao = f4xyz(ps.auxO()[slot]);
                     sd = ps.hit(RAY_NEE)[slot];
-                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, ao, f4xyz(ps.auxDL()[slot])));
+                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, ao, f4xyz(ps.auxDL()[slot]), sc.cullOriginLimit));
                     ps.hit(RAY_NEE)[slot] = sd;
                     sd = ps.hit(RAY_PROBE)[slot];
-                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, ao, f4xyz(ps.auxDC()[slot])));
+                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, ao, f4xyz(ps.auxDC()[slot]), sc.cullOriginLimit));
                     ps.hit(RAY_PROBE)[slot] = sd;
                 }
             }
@@ -1406,6 +1413,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_seed_rays(DevScene sc, PathState p
 }
 
 // ---------------------------------------------------------------- misc kernels
+// start of a multi-kernel dispatch: n active paths and n rays in buffer 0, nothing in buffer 1, work counter 0
+__global__ void k_init_counts(uint32_t* counts, uint32_t n) {
+    if (threadIdx.x == 0) { counts[0] = n; counts[1] = 0; counts[2] = n; counts[3] = 0; counts[4] = 0; }
+}
 __global__ void k_zero_counts(uint32_t* a, uint32_t* b, uint32_t* c) {
     if (threadIdx.x == 0) { *a = 0; *b = 0; *c = 0; }
 }
@@ -1440,6 +1451,16 @@ __global__ void k_selftest(const float* a, const float* b, uint32_t n, uint32_t*
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) hashOut[i] = selftest_one(a[i], b[i]);
     if (i == 0) *bitsOut = rt_selftest_bits(kat);
+}
+
+// include/rt_probe.h on the device: the raw values of every GLSL built-in, for tests/test_glsl_builtins.py
+__global__ void k_math_probe(const float* in, float* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a[32], o[64];
+    for (int k = 0; k < 32; k++) a[k] = in[(size_t)i * 32 + k];
+    rt_math_probe(a, o);
+    for (int k = 0; k < 64; k++) out[(size_t)i * 64 + k] = o[k];
 }
 
 __global__ void k_copy_f4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {

@@ -334,6 +334,15 @@ class Renderer:
         self._check(self._l.rt_device_selftest(self._h, C.byref(b)), "rt_device_selftest")
         return b.value
 
+    def math_probe(self, inputs):
+        """include/rt_probe.h evaluated on the device: [n, 32] float32 -> [n, 64] float32."""
+        x = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 32)
+        out = np.zeros((x.shape[0], 64), dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        self._check(self._l.rt_device_math_probe(self._h, x.shape[0], x.ctypes.data_as(fp), out.ctypes.data_as(fp)),
+                    "rt_device_math_probe")
+        return out
+
     def copy_bandwidth_gbps(self, nbytes=1 << 30, iters=10):
         g = C.c_double()
         self._check(self._l.rt_measure_copy_bandwidth(self._h, nbytes, iters, C.byref(g)), "copy bandwidth")

@@ -11,6 +11,15 @@ totalSamples < sampleLimit; a single render is one dispatch of sampleLimit
 samples per pixel, otherwise each dispatch adds raysPerPixel samples and, when
 progressive, is blended into the fp32 frame with weight 1/(frame+1).
 
+Two deliberate deviations from draw(), both because this is a command that has
+to end and the reference is a window that does not: (1) with singleRender off
+the reference resets totalSamples to 0 after every frame
+(src/vk_engine.cpp:1813-1814), so sampleLimit never stops it; here
+totalSamples accumulates and the loop ends at sampleLimit. (2) With neither
+--progressive nor --single-render every dispatch would be the identical
+frameCount-0 frame (the reference re-renders it until the window closes); here
+exactly one such frame is rendered.
+
 Several GPUs of one node: launch one process per GPU,
 
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
@@ -118,6 +127,7 @@ def main(argv=None):
         import torch.distributed as dist
         from . import tiling
         if args.backend == "nccl":
+            tiling.prepare_rccl_env()
             device = int(os.environ.get("LOCAL_RANK", "0"))
             torch.cuda.set_device(device)
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
@@ -138,6 +148,8 @@ def main(argv=None):
             break
         img = out
         frames += 1
+        if not args.progressive and not args.single_render:
+            break  # every further dispatch would be this very frame again (frameCount does not advance)
     if world > 1 and img is not None:   # strips -> frame on rank 0
         on = f"cuda:{device}" if args.backend == "nccl" else "cpu"
         strip = torch.from_numpy(img).to(on)

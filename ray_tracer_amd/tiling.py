@@ -7,8 +7,17 @@ seeds come from global pixel coordinates (rt_render's row0/rowStride), and one
 gather of the fp32 strips to rank 0 ends the frame. Over RCCL every peer's
 strip (3.1 MB at 1080p/8) goes over its own xGMI link; no ring is needed.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def prepare_rccl_env():
+    """Call before init_process_group("nccl"): this pool's host driver only supports dmabuf IPC, and without
+    HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's peer buffers fail with `hipIpcGetMemHandle: invalid argument`.
+    (Already exported on the GPU boxes; set here for any other launcher.)"""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def rows_of_rank(height, rank, world):

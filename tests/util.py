@@ -41,3 +41,52 @@ def assert_hits_equal(a, b):
             assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), f"field {k} differs at {np.argwhere(x.view(np.uint32) != y.view(np.uint32))[:5].tolist()}"
         else:
             assert np.array_equal(x, y), f"field {k} differs at {np.argwhere(x != y)[:5].tolist()}"
+
+
+class EditedScene:
+    """A Scene whose materials / spheres / objects arrays have been edited in place, the way the reference's ImGui panels
+    edit the host vectors before "Update Buffer" (src/vk_engine.cpp:1536-1618): ctypes copies of the three arrays that the
+    test mutates, handed to rt_update_* and, as the same RtSceneArrays, to the oracle."""
+
+    def __init__(self, scene):
+        import ctypes as C
+        from ray_tracer_amd._capi import RayMaterial, RenderObject, Sphere
+        self.scene = scene
+        a = scene.arrays()
+        self.materials = (RayMaterial * max(a.materialCount, 1))()
+        self.objects = (RenderObject * max(a.objectCount, 1))()
+        self.spheres = (Sphere * max(a.sphereCount, 1))()
+        C.memmove(self.materials, a.materials, C.sizeof(RayMaterial) * a.materialCount)
+        C.memmove(self.objects, a.objects, C.sizeof(RenderObject) * a.objectCount)
+        C.memmove(self.spheres, a.spheres, C.sizeof(Sphere) * a.sphereCount)
+        self.nMaterials, self.nObjects, self.nSpheres = a.materialCount, a.objectCount, a.sphereCount
+
+    def arrays(self):
+        import ctypes as C
+        from ray_tracer_amd._capi import RayMaterial, RenderObject, Sphere
+        a = self.scene.arrays()
+        a.materials = C.cast(self.materials, C.POINTER(RayMaterial))
+        a.objects = C.cast(self.objects, C.POINTER(RenderObject))
+        a.spheres = C.cast(self.spheres, C.POINTER(Sphere))
+        return a
+
+    def counts(self):
+        return self.scene.counts()
+
+    def set_transform(self, i, placement):
+        """objects[i].transformMatrix = T*Rx*Ry*Rz*S of the placement (src/vk_engine.cpp:1597-1601)."""
+        import ctypes as C
+        from ray_tracer_amd import _capi
+        _capi.lib().rt_transform_matrix(C.byref(placement), self.objects[i].transformMatrix)
+
+    def push(self, renderer, what):
+        """update_buffer for one of the arrays (src/vk_engine.cpp:1545,1572,1603)."""
+        l, h = renderer._l, renderer._h
+        if what == "materials":
+            renderer._check(l.rt_update_materials(h, self.materials, self.nMaterials), "rt_update_materials")
+        elif what == "objects":
+            renderer._check(l.rt_update_objects(h, self.objects, self.nObjects), "rt_update_objects")
+        elif what == "spheres":
+            renderer._check(l.rt_update_spheres(h, self.spheres, self.nSpheres), "rt_update_spheres")
+        else:
+            raise KeyError(what)
