@@ -141,6 +141,9 @@ typedef struct RtPlacement {
 } RtPlacement;
 
 enum { RT_MAX_TEXTURES = 64, RT_MAX_MATERIALS = 10, RT_MAX_SPHERES = 10, RT_BVH_BINS = 20 };
+/* Light queries (rt_set_tuning "light_queries") are answered from the list of emissive primitives while the scene's objects
+ * with an emissive material have at most this many triangles between them; beyond it every query is traversed in full. */
+enum { RT_EMIT_MAX_TRIS = 32 };
 
 /* Borrowed views of the scene's host vectors (VulkanEngine members
  * spheres / rayMaterials / triPoints / triangles / objects / bvhNodes,
@@ -226,12 +229,15 @@ typedef struct rt_ctx rt_ctx;
 typedef struct RtCounters {
     uint64_t boxTests;      /* reference stats[0] semantics, raytrace.comp:338, all queries */
     uint64_t triTests;      /* reference stats[1] semantics, raytrace.comp:310, all queries */
-    uint64_t raysTraced;    /* closest-hit queries executed on the device (unique rays) */
+    uint64_t raysTraced;    /* scene queries executed on the device: main rays, and the light queries (NEE ray, cosine probe) that
+                             * their creators could not answer from the emitter list; boxTests / triTests count these queries,
+                             * the light queries up to the hit that answers them */
     uint64_t raysHit;       /* of those, queries that reported a hit */
     uint64_t raysReference; /* queries the reference megakernel would have issued for the same paths */
     uint64_t paths;         /* trace() calls finished (pixel samples) */
     uint64_t segments;      /* path segments shaded */
     uint64_t traceLaunches; /* launches of the traversal kernel */
+    uint64_t emitterTests;  /* emissive primitives tested directly by the creators of light queries (NEE ray, cosine probe) */
 } RtCounters;
 
 /* One closest-hit record of calculateIntersections (raytrace.comp:276-353) */
@@ -291,6 +297,10 @@ int  rt_reset_counters(rt_ctx* ctx);
 int  rt_set_profiling(rt_ctx* ctx, int enabled);
 int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
 /* Performance knobs; none of them changes a pixel or a counter.
+ *   "light_queries"  1 (default): the NEE ray and the cosine probe of a diffuse bounce, which only ask whether their
+ *                    closest hit is emissive and how far it is (raytrace.comp:389-403,443-460), are answered from the list of
+ *                    emissive primitives where that is possible and stop at the first hit that answers them; 0: every one of
+ *                    them is a full closest-hit traversal. Same pixels either way.
  *   "pipeline"       -1 (default) pick by tile size, 0 = multi-kernel wavefront pipeline
  *                    (k_trace_pw + k_shade per round), 1 = wave-private fused pipeline
  *                    (k_render_fused: every wave runs the stages on its own 8x8 pixel blocks)

@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
 class OracleCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "boxTestsReference", "triTestsReference", "raysReference", "raysHitReference",
-        "boxTests", "triTests", "raysTraced", "raysHit", "paths", "segments", "stackOverflow")]
+        "boxTests", "triTests", "raysTraced", "raysHit", "paths", "segments", "stackOverflow", "emitterTests",
+        "lightQueryMismatch")]
 
 
 def effective_cpus():
@@ -59,6 +60,8 @@ def lib():
         l.oracle_trace_rays.restype = C.c_int
         l.oracle_trace_rays.argtypes = [C.POINTER(RtSceneArrays), C.c_uint32, C.c_uint32, C.c_uint32,
                                         C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(RtHit)]
+        l.oracle_set_light_queries.restype = None
+        l.oracle_set_light_queries.argtypes = [C.c_int]
         l.oracle_random.restype = C.c_float
         l.oracle_random.argtypes = [C.POINTER(C.c_uint32)]
         l.oracle_math_probe.restype = None

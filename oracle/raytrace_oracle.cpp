@@ -68,12 +68,18 @@ struct Totals {
     uint64_t boxUnique = 0, triUnique = 0, raysUnique = 0, hitsUnique = 0;
     uint64_t paths = 0, segments = 0;
     uint64_t stackOverflow = 0;
+    uint64_t emitterTests = 0, lightQueryMismatch = 0;
 };
 
 struct Scene {
     RtSceneArrays a;
     uint32_t sphereCount, objectCount;
     std::vector<float> inv;  // inverse(object.transformMatrix), 16 floats per object
+    // The wavefront pipeline's light queries (its definition of "executed work", see executed_light_query below):
+    // every triangle of every object with an emissive material, the emissive spheres, and whether the shortcut applies.
+    std::vector<std::pair<uint32_t, uint32_t>> emitTris;  // {object, triangle}
+    uint32_t emitSphereMask = 0;
+    bool emitMode = false;
 };
 
 // raytrace.comp:195-224
@@ -148,7 +154,9 @@ float boxIntersection(const BVHNode& n, const rt_vec3& origin, const rt_vec3& in
 }
 
 // raytrace.comp:276-353
-HitInfo calculateIntersections(const Scene& sc, const Ray& ray, Tally& stats, uint64_t* overflow) {
+// earlyT > 0 is not part of the shader: it is how the wavefront pipeline executes a light query (see
+// executed_light_query) and only ever feeds the "executed work" counters, never a pixel.
+HitInfo calculateIntersections(const Scene& sc, const Ray& ray, Tally& stats, uint64_t* overflow, float earlyT = 0.f) {
     HitInfo closestHit;
     closestHit.didHit = false;
     closestHit.dst = RT_MISS_DST;
@@ -189,6 +197,11 @@ HitInfo calculateIntersections(const Scene& sc, const Ray& ray, Tally& stats, ui
                         closestHit.triHitIndex = j;
                         closestHit.objectHitIndex = i;
                     }
+                }
+                if (closestHit.didHit && closestHit.dst < earlyT) {  // answered: nearer than the nearest emissive primitive
+                    HitInfo none;
+                    none.dst = RT_MISS_DST;
+                    return none;
                 }
             } else {
                 const BVHNode& c1 = sc.a.bvhNodes[node.index];
@@ -275,6 +288,34 @@ float cosineHemispherePDF(const rt_vec3& n, const rt_vec3& direction) {
     return rt_max(0.f, rt_dot(direction, n) * RT_INV_PI);
 }
 
+// ---- the wavefront pipeline's light queries (ray_tracer_amd/csrc/rt_kernels.hip.h: emitter_min_t, trace_wave's leaf step).
+// The NEE ray and the cosine probe of a diffuse bounce only ask whether their closest hit is emissive and how far it is
+// (raytrace.comp:389-403,443-460). The pipeline tests the emissive primitives directly (no boxes), which gives tE, the
+// nearest of them on the ray; if there is none, or a sphere is nearer, it does not trace the ray; otherwise it traverses and
+// stops at the first triangle hit nearer than tE. This function restates that, for the "executed work" counters the GPU
+// tests compare, and checks the answer against the shader's own closest hit (lightQueryMismatch must stay 0).
+float emitter_min_t(const Scene& sc, const Ray& ray, uint64_t& tested) {
+    float tE = RT_MISS_DST;
+    for (uint32_t i = 0; i < sc.sphereCount && i < 32; i++) {
+        if (!((sc.emitSphereMask >> i) & 1u)) continue;
+        HitInfo h = sphereIntersection(sc.a.spheres[i], ray);
+        if (h.didHit && h.dst < tE) tE = h.dst;
+        tested++;
+    }
+    for (const auto& e : sc.emitTris) {
+        if (e.first >= sc.objectCount) continue;
+        const float* inv = &sc.inv[(size_t)e.first * 16];
+        Ray tr;
+        tr.dir = rt_xform_dir(inv, ray.dir);
+        tr.origin = rt_xform_point(inv, ray.origin);
+        const Triangle& tri = sc.a.triangles[e.second];
+        HitInfo h = triangleIntersection(tr, sc.a.triPoints[tri.v0], sc.a.triPoints[tri.v1], sc.a.triPoints[tri.v2], tri.frontOnly != 0);
+        if (h.didHit && h.dst < tE) tE = h.dst;
+        tested++;
+    }
+    return tE;
+}
+
 struct PathCtx {
     const Scene& sc;
     const PushConstants& pc;
@@ -288,12 +329,36 @@ void tally_unique(PathCtx& c, const Tally& t, const HitInfo& h) {
     c.tot.boxUnique += t.box; c.tot.triUnique += t.tri; c.tot.raysUnique++; c.tot.hitsUnique += h.didHit;
 }
 
+// What the pipeline executes for one light query, and whether its answer is the shader's (`full` = the shader's closest hit).
+void executed_light_query(PathCtx& c, const Ray& ray, const Tally& fullTally, const HitInfo& full) {
+    if (!c.sc.emitMode) { tally_unique(c, fullTally, full); return; }
+    const float tE = emitter_min_t(c.sc, ray, c.tot.emitterTests);
+    float sphereBest = RT_MISS_DST;
+    for (uint32_t i = 0; i < c.sc.sphereCount; i++) {
+        HitInfo h = sphereIntersection(c.sc.a.spheres[i], ray);
+        if (h.didHit && h.dst < sphereBest) sphereBest = h.dst;
+    }
+    const bool fullEmissive = full.didHit && !(c.sc.a.materials[full.materialIndex].emissionStrength == 0.f);
+    if (!(tE < RT_MISS_DST) || sphereBest < tE) {  // answered by the ray's creator: "not emissive"
+        if (fullEmissive) c.tot.lightQueryMismatch++;
+        return;
+    }
+    Tally t;
+    HitInfo h = calculateIntersections(c.sc, ray, t, nullptr, tE);
+    tally_unique(c, t, h);
+    if (h.didHit) {  // ran to the end: the shader's closest hit itself
+        if (!full.didHit || h.dst != full.dst || h.objectHitIndex != full.objectHitIndex || h.isSphere != full.isSphere) c.tot.lightQueryMismatch++;
+    } else if (fullEmissive) {
+        c.tot.lightQueryMismatch++;
+    }
+}
+
 // raytrace.comp:430-464. `auxNeeded` says whether the wavefront pipeline
 // would have traced the two probe rays (it skips them when the path ends at
 // this bounce, because directLight/misWeight are then never read); the
 // oracle always traces them, as the shader does, and only files the tallies
 // under different counters.
-BxDFResult diffuseBRDF(PathCtx& c, const HitInfo& prevHit, uint32_t& state, Tally aux[3], HitInfo auxHit[3]) {
+BxDFResult diffuseBRDF(PathCtx& c, const HitInfo& prevHit, uint32_t& state, Tally aux[3], HitInfo auxHit[3], Ray auxRay[2]) {
     const RayMaterial& hitMaterial = c.sc.a.materials[prevHit.materialIndex];
     rt_vec3 albedo = rt_v3(hitMaterial.albedo[0], hitMaterial.albedo[1], hitMaterial.albedo[2]);
     rt_vec3 origin = rt_add(prevHit.hitPoint, rt_scale(prevHit.normal, 0.01f));
@@ -302,6 +367,7 @@ BxDFResult diffuseBRDF(PathCtx& c, const HitInfo& prevHit, uint32_t& state, Tall
     rt_vec3 cosineSample = cosineHemisphereDir(prevHit.normal, state);
 
     Ray lightRay{origin, lightSample};
+    auxRay[0] = lightRay;
     HitInfo lightHit = calculateIntersections(c.sc, lightRay, aux[0], &c.tot.stackOverflow);  // :443
     auxHit[0] = lightHit;
     const RayMaterial& lightMaterial = c.sc.a.materials[lightHit.didHit ? lightHit.materialIndex : 0];
@@ -314,6 +380,7 @@ BxDFResult diffuseBRDF(PathCtx& c, const HitInfo& prevHit, uint32_t& state, Tall
     if (rt_isnan(misWeight1)) misWeight1 = 0.f;
 
     Ray probe{origin, cosineSample};
+    auxRay[1] = probe;
     HitInfo probeHit = calculateIntersections(c.sc, probe, aux[2], &c.tot.stackOverflow);    // :453
     auxHit[2] = probeHit;
     float lightPDF = lightSamplePDF_fromHit(c.sc, probeHit, cosineSample);
@@ -383,12 +450,13 @@ rt_vec3 trace(PathCtx& c, Ray ray, uint32_t& state, Tally& mainStats) {
             bool diffuse = false;
             Tally aux[3];
             HitInfo auxHit[3];
+            Ray auxRay[2];
             if (m.reflectance != 0.f) {
                 bxdf = specularBRDF(newRay.dir, hit);
             } else if (m.ior != -1.f) {
                 bxdf = dielectricBTDF(c, newRay.dir, hit, state);
             } else {
-                bxdf = diffuseBRDF(c, hit, state, aux, auxHit);
+                bxdf = diffuseBRDF(c, hit, state, aux, auxHit, auxRay);
                 diffuse = true;
             }
             attenuation = rt_mul(attenuation, bxdf.radiance);
@@ -403,8 +471,8 @@ rt_vec3 trace(PathCtx& c, Ray ray, uint32_t& state, Tally& mainStats) {
                 // the pipeline traces the NEE ray and the cosine probe once each,
                 // and only when a later segment can read their results
                 if (!rrBreak && j < bounceLimit) {
-                    tally_unique(c, aux[0], auxHit[0]);
-                    tally_unique(c, aux[2], auxHit[2]);
+                    executed_light_query(c, auxRay[0], aux[0], auxHit[0]);
+                    executed_light_query(c, auxRay[1], aux[2], auxHit[2]);
                 }
             }
             if (rrBreak) break;
@@ -468,13 +536,47 @@ void pixel_main(PathCtx& c, uint32_t gx, uint32_t gy, uint32_t W, uint32_t H, fl
     rgba[0] = finalColor.x; rgba[1] = finalColor.y; rgba[2] = finalColor.z; rgba[3] = 1.f;
 }
 
-Scene make_scene(const RtSceneArrays* a, uint32_t sphereCount, uint32_t objectCount) {
+Scene make_scene(const RtSceneArrays* a, uint32_t sphereCount, uint32_t objectCount, bool lightQueries = true) {
     Scene sc;
     sc.a = *a;
     sc.sphereCount = sphereCount;
     sc.objectCount = objectCount;
     sc.inv.resize((size_t)objectCount * 16);
     for (uint32_t i = 0; i < objectCount; i++) rt_mat4_inverse(a->objects[i].transformMatrix, &sc.inv[(size_t)i * 16]);
+    // the emitter list, by the rules of rt_device.hip's rebuild_emitters (over the UPLOADED scene: a->sphereCount / a->objectCount)
+    auto emissive = [&](uint32_t m) { return m < a->materialCount && !(a->materials[m].emissionStrength == 0.f); };
+    bool ok = lightQueries;
+    for (uint32_t m = 0; m < a->materialCount && ok; m++)
+        for (int k = 0; k < 3; k++) {
+            float p = a->materials[m].emissionColor[k] * a->materials[m].emissionStrength;
+            if (rt_isnan(p) || rt_isinf(p)) ok = false;
+        }
+    for (uint32_t i = 0; i < a->sphereCount && ok; i++)
+        if (emissive(a->spheres[i].materialIndex)) {
+            if (i < 32) sc.emitSphereMask |= 1u << i; else ok = false;
+        }
+    for (uint32_t i = 0; i < a->objectCount && ok; i++) {
+        if (!emissive(a->objects[i].materialIndex)) continue;
+        std::vector<uint32_t> st{a->objects[i].bvhIndex};
+        uint64_t lo = ~0ull, hi = 0, sum = 0;
+        while (!st.empty()) {
+            const BVHNode& n = a->bvhNodes[st.back()];
+            st.pop_back();
+            if (n.triCount) {
+                lo = lo < n.index ? lo : n.index;
+                hi = hi > (uint64_t)n.index + n.triCount ? hi : (uint64_t)n.index + n.triCount;
+                sum += n.triCount;
+            } else {
+                st.push_back(n.index);
+                st.push_back(n.index + 1);
+            }
+            if (sum > RT_EMIT_MAX_TRIS) break;
+        }
+        if (sum != hi - lo || sc.emitTris.size() + sum > (size_t)RT_EMIT_MAX_TRIS) { ok = false; break; }
+        for (uint64_t t = lo; t < hi; t++) sc.emitTris.emplace_back(i, (uint32_t)t);
+    }
+    sc.emitMode = ok;
+    if (!ok) { sc.emitTris.clear(); sc.emitSphereMask = 0; }
     return sc;
 }
 
@@ -484,17 +586,23 @@ void add_totals(OracleCounters& o, const Totals& t) {
     o.boxTests += t.boxUnique; o.triTests += t.triUnique;
     o.raysTraced += t.raysUnique; o.raysHit += t.hitsUnique;
     o.paths += t.paths; o.segments += t.segments; o.stackOverflow += t.stackOverflow;
+    o.emitterTests += t.emitterTests; o.lightQueryMismatch += t.lightQueryMismatch;
 }
+
+bool g_lightQueries = true;
 
 }  // namespace
 
 extern "C" {
 
+// mirrors rt_set_tuning("light_queries", v): which definition of "executed work" the counters follow (pixels never change)
+void oracle_set_light_queries(int on) { g_lightQueries = on != 0; }
+
 int oracle_render(const RtSceneArrays* scene, const PushConstants* pc, uint32_t width, uint32_t height, uint32_t row0,
                   uint32_t rowStride, uint32_t nRows, float* rgba, OracleCounters* counters, int threads) {
     if (!scene || !pc || !rgba || rowStride == 0) return -1;
     if (pc->rayTraceParams.sphereCount > scene->sphereCount || pc->rayTraceParams.objectCount > scene->objectCount) return -2;
-    Scene sc = make_scene(scene, pc->rayTraceParams.sphereCount, pc->rayTraceParams.objectCount);
+    Scene sc = make_scene(scene, pc->rayTraceParams.sphereCount, pc->rayTraceParams.objectCount, g_lightQueries);
     if (threads < 1) threads = 1;
     std::vector<Totals> totals(threads);
     // work items are 64-pixel runs of a row so that many threads stay busy on few rows

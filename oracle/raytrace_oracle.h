@@ -18,6 +18,8 @@ typedef struct OracleCounters {
     uint64_t boxTests, triTests, raysTraced, raysHit;
     uint64_t paths, segments;
     uint64_t stackOverflow; /* traversals that needed more than the shader's 64-entry stack */
+    uint64_t emitterTests;  /* emissive primitives the pipeline's light queries test directly (RtCounters.emitterTests) */
+    uint64_t lightQueryMismatch; /* light queries whose shortcut answer differs from the shader's closest hit: must be 0 */
 } OracleCounters;
 
 /* One dispatch of raytrace.comp main() over rows row0 + k*rowStride.
@@ -27,6 +29,7 @@ int oracle_render(const RtSceneArrays* scene, const PushConstants* pc, uint32_t 
 /* calculateIntersections (raytrace.comp:276-353) per ray */
 int oracle_trace_rays(const RtSceneArrays* scene, uint32_t sphereCount, uint32_t objectCount, uint32_t n,
                       const float* origins, const float* dirs, RtHit* out);
+void oracle_set_light_queries(int on);
 float oracle_random(uint32_t* state);
 void oracle_math_probe(float x, float y, float out[8]);
 void oracle_mat4_inverse(const float m[16], float out[16]);

@@ -83,7 +83,7 @@ class RtSceneArrays(C.Structure):
 
 class RtCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference",
-                                          "paths", "segments", "traceLaunches")]
+                                          "paths", "segments", "traceLaunches", "emitterTests")]
 
 
 class RtHit(C.Structure):

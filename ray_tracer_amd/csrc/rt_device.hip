@@ -26,7 +26,7 @@ struct DevBuf {
 
 struct EventPair { hipEvent_t a, b; };
 // device-side {index,triCount} of a mesh root, keyed by its reference node index
-struct RootInfo { uint32_t idx, cnt; float lo[3], hi[3]; };
+struct RootInfo { uint32_t idx, cnt; float lo[3], hi[3]; uint32_t triFirst, triTotal; };  // triTotal = ~0u: the mesh's triangles are not one contiguous range
 
 }  // namespace
 
@@ -39,7 +39,11 @@ struct rt_ctx {
     // scene
     DevScene sc{};
     std::vector<DevBuf> sceneBufs;
-    DevBuf matBuf, sphereBuf, sphereMatBuf, objInvBuf, objFwdBuf, objMetaBuf, objBoxBuf, objSkipBuf, maskBoxBuf;
+    DevBuf matBuf, sphereBuf, sphereMatBuf, objInvBuf, objFwdBuf, objMetaBuf, objBoxBuf, objSkipBuf, maskBoxBuf, emitBuf;
+    // host copies of what the emitter list is derived from (rebuild_emitters)
+    std::vector<RayMaterial> hostMats;
+    std::vector<uint32_t> hostSphereMat, hostObjMat, hostObjRoot;
+    int lightQueries = 1;   // rt_set_tuning("light_queries", 0): trace every NEE ray and cosine probe in full
     uint32_t maxLeafDepth = 0;
     std::vector<uint32_t> nodeRemap;          // reference node index -> device node index
     std::vector<RootInfo> rootOf;             // per reference node; idx = ~0u unless a mesh root
@@ -384,6 +388,43 @@ int harvest_events(rt_ctx* c) {
     return 0;
 }
 
+// The emitter list of the light queries (rt_kernels.hip.h: emitter_min_t): every triangle of every object whose material is
+// emissive, and the emissive spheres. "Emissive" is what lightSamplePDF asks (raytrace.comp:392): emissionStrength != 0.
+// The shortcut is only taken when it is cheap (at most RT_EMIT_MAX_TRIS triangles) and exact: the NEE term of a query that
+// is answered "not emissive" is emission * 0, which is 0 only while every material's emissionColor * emissionStrength is finite.
+int rebuild_emitters(rt_ctx* c) {
+    c->sc.emitCount = 0; c->sc.emitSphereMask = 0; c->sc.emitMode = 0;
+    if (!c->lightQueries || c->hostMats.empty()) return 0;
+    auto emissive = [&](uint32_t m) { return m < c->hostMats.size() && !(c->hostMats[m].emissionStrength == 0.f); };
+    for (const RayMaterial& m : c->hostMats)
+        for (int k = 0; k < 3; k++)
+            if (!std::isfinite(m.emissionColor[k] * m.emissionStrength)) return 0;
+    uint32_t mask = 0;
+    for (size_t i = 0; i < c->hostSphereMat.size() && i < 32; i++)
+        if (emissive(c->hostSphereMat[i])) mask |= 1u << i;
+    for (size_t i = 32; i < c->hostSphereMat.size(); i++)
+        if (emissive(c->hostSphereMat[i])) return 0;  // beyond the mask (the reference has ten spheres)
+    std::vector<uint2> list;
+    for (size_t i = 0; i < c->hostObjMat.size(); i++) {
+        if (!emissive(c->hostObjMat[i])) continue;
+        const RootInfo& r = c->rootOf[c->hostObjRoot[i]];
+        if (r.triTotal == 0xffffffffu || list.size() + r.triTotal > (size_t)RT_EMIT_MAX_TRIS) return 0;
+        for (uint32_t t = 0; t < r.triTotal; t++) list.push_back(make_uint2((uint32_t)i, r.triFirst + t));
+    }
+    if (!list.empty()) {
+        int rc = upload(c, c->emitBuf, list.data(), list.size() * sizeof(uint2));
+        if (rc) return rc;
+    } else {
+        int rc = dev_alloc(c, c->emitBuf, 256);
+        if (rc) return rc;
+    }
+    c->sc.emitTris = (const uint2*)c->emitBuf.p;
+    c->sc.emitCount = (uint32_t)list.size();
+    c->sc.emitSphereMask = mask;
+    c->sc.emitMode = 1;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -427,7 +468,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->sceneBufs) dev_free(b);
-    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->stateBuf,
+    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->emitBuf, &c->stateBuf,
                       &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf, &c->waveTimeBuf, &c->probeBuf})
         dev_free(*b);
     for (auto& e : c->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -457,7 +498,8 @@ int rt_update_materials(rt_ctx* c, const RayMaterial* m, uint32_t n) {
     if (rc) return rc;
     c->sc.mats = (const float4*)c->matBuf.p;
     c->sc.materialCount = n;
-    return 0;
+    c->hostMats.assign(m, m + n);
+    return rebuild_emitters(c);
 }
 
 int rt_update_spheres(rt_ctx* c, const Sphere* s, uint32_t n) {
@@ -476,7 +518,8 @@ int rt_update_spheres(rt_ctx* c, const Sphere* s, uint32_t n) {
     c->sc.spheres = (const float4*)c->sphereBuf.p;
     c->sc.sphereMat = (const uint32_t*)c->sphereMatBuf.p;
     c->sc.sphereCount = n;
-    return 0;
+    c->hostSphereMat.assign(sm.begin(), sm.begin() + n);
+    return rebuild_emitters(c);
 }
 
 // objects: inverse computed once on the host with the shared
@@ -588,7 +631,9 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
     c->sc.objFwd = (const float4*)c->objFwdBuf.p;
     c->sc.objMeta = (const uint4*)c->objMetaBuf.p;
     c->sc.objectCount = n;
-    return 0;
+    c->hostObjMat.resize(n); c->hostObjRoot.resize(n);
+    for (uint32_t i = 0; i < n; i++) { c->hostObjMat[i] = o[i].materialIndex; c->hostObjRoot[i] = o[i].bvhIndex; }
+    return rebuild_emitters(c);
 }
 
 }  // extern "C"
@@ -601,6 +646,8 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
     RT_HIP(c, hipStreamSynchronize(c->stream));
     if (c->snapPending) { c->snapBox = c->snap->boxTests; c->snapRays = c->snap->raysTraced; c->snapPending = false; }
     c->boxPerRay = -1.0;  // a new scene: its ray cost is not known yet
+    c->hostObjMat.clear(); c->hostObjRoot.clear(); c->hostSphereMat.clear(); c->hostMats.clear();
+    c->sc.emitMode = 0; c->sc.emitCount = 0; c->sc.emitSphereMask = 0;
     const uint32_t nNodes = s->bvhNodeCount, nTris = s->triangleCount;
 
     // ---- mesh segmentation: every distinct object.bvhIndex starts a mesh
@@ -670,25 +717,32 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
 
     // ---- deepest leaf per mesh decides the LDS stack size
     std::vector<RootInfo>& rootOf = c->rootOf;
-    rootOf.assign(nNodes, RootInfo{0xffffffffu, 0, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}});
+    rootOf.assign(nNodes, RootInfo{0xffffffffu, 0, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0u, 0u});
     uint32_t maxDepth = 0;
     {
         std::vector<std::pair<uint32_t, uint32_t>> st;
         for (uint32_t root : roots) {
             const BVHNode& rb = s->bvhNodes[root];
-            rootOf[root] = RootInfo{node_word(root), rb.triCount, {rb.boundsX[0], rb.boundsY[0], rb.boundsZ[0]}, {rb.boundsX[1], rb.boundsY[1], rb.boundsZ[1]}};
+            rootOf[root] = RootInfo{node_word(root), rb.triCount, {rb.boundsX[0], rb.boundsY[0], rb.boundsZ[0]}, {rb.boundsX[1], rb.boundsY[1], rb.boundsZ[1]}, 0u, 0u};
             st.clear();
             st.emplace_back(root, 0u);
             size_t visited = 0;
+            uint64_t triLo = ~0ull, triHi = 0, triSum = 0;  // the mesh's triangles: the leaves' ranges, one contiguous run as the builder leaves them
             while (!st.empty()) {
                 auto [nidx, d] = st.back();
                 st.pop_back();
                 if (++visited > (size_t)nNodes + 1) return c->fail("BVH has a cycle");
                 const BVHNode& b = s->bvhNodes[nidx];
-                if (b.triCount) { maxDepth = std::max(maxDepth, d); continue; }
+                if (b.triCount) {
+                    maxDepth = std::max(maxDepth, d);
+                    triLo = std::min<uint64_t>(triLo, b.index); triHi = std::max<uint64_t>(triHi, (uint64_t)b.index + b.triCount); triSum += b.triCount;
+                    continue;
+                }
                 st.emplace_back(b.index, d + 1);
                 st.emplace_back(b.index + 1, d + 1);
             }
+            rootOf[root].triFirst = (uint32_t)triLo;
+            rootOf[root].triTotal = (triSum == triHi - triLo) ? (uint32_t)triSum : 0xffffffffu;
         }
     }
     if (maxDepth > 64) return c->fail("BVH deeper than 64 levels (the reference's builder caps at 64)");
@@ -998,6 +1052,7 @@ int rt_get_counters(rt_ctx* c, RtCounters* out) {
     out->boxTests = h.boxTests; out->triTests = h.triTests; out->raysTraced = h.raysTraced; out->raysHit = h.raysHit;
     out->raysReference = h.raysReference; out->paths = h.paths; out->segments = h.segments;
     out->traceLaunches = c->traceLaunchesTotal;
+    out->emitterTests = h.emitterTests;
     if (c->phaseStats) {
         unsigned long long ps[12];
         RT_HIP(c, hipMemcpy(ps, (char*)c->counterBuf.p + sizeof(DevCounters), sizeof(ps), hipMemcpyDeviceToHost));
@@ -1058,6 +1113,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     std::string k(key);
     if (k == "pipeline") { if (value < -1 || value > 1) return c->fail("pipeline: -1 (auto), 0 or 1"); c->pipeline = value; }
     else if (k == "probe") { c->probe = value ? 1 : 0; }
+    else if (k == "light_queries") { c->lightQueries = value ? 1 : 0; int rc = rebuild_emitters(c); if (rc) return rc; }
     else if (k == "fused_below_box_tests") { if (value < 0) return c->fail("fused_below_box_tests >= 0"); c->fusedBelowBoxTests = (uint32_t)value; }
     else if (k == "fused_below_pixels") { if (value < 0) return c->fail("fused_below_pixels >= 0"); c->fusedBelowPixels = (uint32_t)value; }
     else if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }

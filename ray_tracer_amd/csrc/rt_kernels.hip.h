@@ -70,6 +70,13 @@ struct DevScene {
     const float4* maskBox;   // reachCount x 2 float4: the objects a ray's creator tests for the ray's object mask (reach_mask_from)
     const uint2* objSkipCost; // 33 entries: {box tests, triangle tests} the reference spends on objects [0, i) when a ray misses them all
     uint32_t reachCount;     // entries of maskBox
+    // Light queries (the NEE ray and the cosine probe of a diffuse bounce, raytrace.comp:443-453) only ask "is the closest hit
+    // emissive, and how far is it". emitTris lists every triangle of every object whose material is emissive ({object,
+    // triangle}, sorted by object), emitSphereMask the emissive spheres; the creator of such a ray tests them all and knows the
+    // nearest emissive primitive's distance tE before any traversal (emitter_min_t). emitMode 0: too many emissive triangles
+    // (or non-finite emission values): every light query is traversed in full, as round 1 did.
+    const uint2* emitTris;
+    uint32_t emitCount, emitSphereMask, emitMode;
     float cullOriginLimit;   // rays that start farther out than this (max |origin component|) skip nothing: the padding of the world-space
                              // boxes (1e-3 of an object's size and position) only dominates the slab tests' rounding, which grows with
                              // |origin|, while the origin is within 1e3 object scales (rt_update_objects)
@@ -126,7 +133,7 @@ struct FrameParams {
 };
 
 struct DevCounters {
-    unsigned long long boxTests, triTests, raysTraced, raysHit, raysReference, paths, segments, pad;
+    unsigned long long boxTests, triTests, raysTraced, raysHit, raysReference, paths, segments, emitterTests;
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -286,6 +293,44 @@ __device__ __forceinline__ void box_intersect_pair(float4 q0, float4 q1, float4 
     d2 = (fR >= nR && fR > 0.f) ? (nR > 0.f ? nR : 0.f) : RT_MISS_DST;
 }
 
+// Distance of the nearest emissive primitive the ray (ro, rd) hits at all, RT_MISS_DST if it hits none: the emissive spheres
+// and every listed triangle, each tested with the operations the traversal would use (sphere_intersect; the object-space
+// ray of reconstruct_hit and tri_intersect), no bounding boxes involved. Whatever calculateIntersections finds for this ray,
+// an emissive closest hit has exactly one of the distances minimised here, so:
+//   * tE == RT_MISS_DST: the closest hit cannot be emissive -> lightSamplePDF is 0 and the NEE term is 0 (raytrace.comp:
+//     389-403,443-460) whatever the ray hits; the ray is not traced at all;
+//   * a hit nearer than tE (a sphere, found by the creator, or a triangle, found by the traversal) is not emissive and
+//     the closest hit is at least as near: same conclusion, the traversal stops there (trace_wave, leaf step).
+// Both are statements about computed values only (the minimum of the very numbers the traversal compares), not about
+// geometry, so they hold bit for bit.
+__device__ __forceinline__ float emitter_min_t(const DevScene& sc, rt_vec3 ro, rt_vec3 rd, uint32_t& tested) {
+    float tE = RT_MISS_DST;
+    for (uint32_t m = sc.emitSphereMask; m; m &= m - 1u) {
+        const uint32_t i = (uint32_t)__ffs((int)m) - 1u;
+        if (i >= sc.sphereCount) break;
+        const SphereHit h = sphere_intersect(sc.spheres[i], ro, rd);
+        if (h.didHit && h.dst < tE) tE = h.dst;
+        tested++;
+    }
+    uint32_t curObj = 0xffffffffu;
+    rt_vec3 tro = ro, trd = rd;
+    for (uint32_t k = 0; k < sc.emitCount; k++) {
+        const uint2 e = sc.emitTris[k];
+        if (e.x >= sc.objectCount) break;  // a dispatch with fewer objects than were uploaded (sorted by object)
+        if (e.x != curObj) {
+            curObj = e.x;
+            const float4 i0 = sc.objInv[3 * curObj], i1 = sc.objInv[3 * curObj + 1], i2 = sc.objInv[3 * curObj + 2];
+            trd = xform_dir_rows(i0, i1, i2, rd);
+            tro = xform_point_rows(i0, i1, i2, ro);
+        }
+        const float4 a = sc.triPos[3 * (size_t)e.y], b = sc.triPos[3 * (size_t)e.y + 1], c = sc.triPos[3 * (size_t)e.y + 2];
+        const TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
+        if (h.didHit && h.dst < tE) tE = h.dst;
+        tested++;
+    }
+    return tE;
+}
+
 // ---------------------------------------------------------------- leaf references
 #define RT_LEAF_CNT_SHIFT 28
 #define RT_LEAF_IDX_MASK 0x0fffffffu
@@ -335,6 +380,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
 
         float best = RT_MISS_DST;
         uint32_t bestObj = RT_HIT_NONE, bestTri = 0;
+        const float earlyT = ta.queue ? ps.hit(kind)[slot].w : 0.f;  // light queries: distance of the nearest emissive primitive
 
         for (uint32_t i = 0; i < sc.sphereCount; i++) {
             SphereHit h = sphere_intersect(sc.spheres[i], ro, rd);
@@ -371,12 +417,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
             }
             if (curCnt != 0) {
                 nTri += curCnt;
+                bool closer = false;
                 for (uint32_t j = curIdx; j < curIdx + curCnt; j++) {
                     float4 a = sc.triPos[3 * j], b = sc.triPos[3 * j + 1], c = sc.triPos[3 * j + 2];
                     TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
-                    if (h.didHit && h.dst < best) { best = h.dst; bestObj = obj - 1; bestTri = j; }
+                    if (h.didHit && h.dst < best) { best = h.dst; bestObj = obj - 1; bestTri = j; closer = true; }
                 }
                 have = false;
+                // a light query that found something nearer than its nearest emissive primitive is answered (see trace_wave)
+                if (closer && best < earlyT) { best = RT_MISS_DST; bestObj = RT_HIT_NONE; bestTri = 0; break; }
             } else {
                 const float4* pr = sc.nodes + 2 * (size_t)curIdx;
                 float4 lo1 = pr[0], hi1 = pr[1], lo2 = pr[2], hi2 = pr[3];
@@ -601,6 +650,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         cur = (cnt > take) ? (cur + take - (take << RT_LEAF_CNT_SHIFT)) : RT_CUR_NEED;
                     }
                     if (PIX) rayTri += jEnd - j; else wt.totTri += jEnd - j;
+                    bool closer = false;  // this step found a nearer hit
                     if (cnt != 0u) {
                         // one or two triangles: both fetched before either is tested
                         const uint32_t j1 = jEnd - 1u;
@@ -608,17 +658,40 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         const float4 a1 = sc.triPos[3 * (size_t)j1], b1 = sc.triPos[3 * (size_t)j1 + 1], c1 = sc.triPos[3 * (size_t)j1 + 2];
                         const rt_vec3 o = rt_v3(troXY.x, troXY.y, zOI.x);
                         const TriHit h0 = tri_intersect(o, trd, f4xyz(a0), f4xyz(b0), f4xyz(c0), __float_as_uint(a0.w) != 0u);
-                        if (h0.didHit && h0.dst < best) { best = h0.dst; bestObj = cur_object(); bestTri = j; }
+                        if (h0.didHit && h0.dst < best) { best = h0.dst; bestObj = cur_object(); bestTri = j; closer = true; }
                         if (j1 != j) {
                             const TriHit h1 = tri_intersect(o, trd, f4xyz(a1), f4xyz(b1), f4xyz(c1), __float_as_uint(a1.w) != 0u);
-                            if (h1.didHit && h1.dst < best) { best = h1.dst; bestObj = cur_object(); bestTri = j1; }
+                            if (h1.didHit && h1.dst < best) { best = h1.dst; bestObj = cur_object(); bestTri = j1; closer = true; }
                         }
                     } else {
                         for (; j < jEnd; j++) {
                             const float4 a = sc.triPos[3 * (size_t)j], b = sc.triPos[3 * (size_t)j + 1], c = sc.triPos[3 * (size_t)j + 2];
                             const TriHit h = tri_intersect(rt_v3(troXY.x, troXY.y, zOI.x), trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
-                            if (h.didHit && h.dst < best) { best = h.dst; bestObj = cur_object(); bestTri = j; }
+                            if (h.didHit && h.dst < best) { best = h.dst; bestObj = cur_object(); bestTri = j; closer = true; }
                         }
+                    }
+                    // Light queries carry tE, the distance of the nearest emissive primitive they hit at all (emitter_min_t; 0 for
+                    // every other ray). A hit nearer than tE is not emissive and the closest hit is no farther: the query's answer
+                    // is "not emissive" whatever else the ray meets, so it ends here and reports no hit, which is what shade_path
+                    // reads as "not emissive". tE is re-read from the ray's hit record on the rare step that finds a hit rather
+                    // than held in a register through the loop. The leaf counts in full, as the shader counts it (:310).
+                    if (closer && best < ps.hit(id & 3u)[id >> 2].w) {
+                        if ((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX) {  // triangles of this leaf not yet stepped through
+                            const uint32_t rest = (cur >> RT_LEAF_CNT_SHIFT) & 7u;
+                            if (PIX) rayTri += rest; else wt.totTri += rest;
+                        }
+                        if (CULL) {
+                            // the objects after this one that the ray's mask rules out were charged when this one was entered
+                            // (fetch_next_meta); the query ends before the reference's loop would have reached them
+                            const uint32_t ahead = nxFlags >> 8;
+                            if (ahead) {
+                                const uint2 c0 = sc.objSkipCost[obj - ahead], c1 = sc.objSkipCost[obj];
+                                if (PIX) { rayBox -= c1.x - c0.x; rayTri -= c1.y - c0.y; } else { wt.totBox -= c1.x - c0.x; wt.totTri -= c1.y - c0.y; }
+                            }
+                        }
+                        best = RT_MISS_DST; bestObj = RT_HIT_NONE; bestTri = 0;
+                        sp = 0; obj = sc.objectCount;
+                        cur = RT_CUR_NEED;
                     }
                 }
             } else if (runS) {
@@ -931,10 +1004,13 @@ struct ShadeArgs {
 
 // One path, one segment: trace()'s loop body (raytrace.comp:495-534) with diffuseBRDF split around the
 // probe rays, plus main()'s sample loop (:571-573). Reads the hit records of the path's rays, writes
-// its next rays. Outputs: alive (a main ray was emitted), wantAux (and two probe rays), refRays (the
-// shader's calculateIntersections calls for this segment), nPaths (1 if a sample finished).
+// its next rays. Outputs: alive (a main ray was emitted), auxMask (bit 0: the NEE ray, bit 1: the cosine probe of this
+// diffuse bounce have to be traced; a light query that emitter_min_t answers is not), refRays (the shader's
+// calculateIntersections calls for this segment), nPaths (1 if a sample finished), emitTests (primitives emitter_min_t tested).
 __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& ps, const FrameParams& fp, uint32_t slot, bool& alive,
-                                           bool& wantAux, uint32_t& refRays, uint32_t& nPaths, bool withMask = true) {
+                                           uint32_t& auxMask, uint32_t& refRays, uint32_t& nPaths, uint32_t& emitTests, bool withMask = true) {
+    bool wantAux = false;  // a diffuse bounce whose MIS the next segment finishes (raytrace.comp:443-460)
+    auxMask = 0;
     rt_vec3 auxOrigin = rt_v3(0, 0, 0), auxL = auxOrigin, auxC = auxOrigin;  // probe rays of this bounce (diffuse only)
     const float4 sO = ps.rayO()[slot], sD = ps.rayD()[slot], sA = ps.att()[slot], sT = ps.total()[slot], sDi = ps.direct()[slot];
     const float4 hM = ps.hit(RAY_MAIN)[slot];
@@ -1101,8 +1177,21 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
     if (alive) {
         ps.hit(RAY_MAIN)[slot] = sphere_seed(sc, ro, rd, withMask);
         if (wantAux) {
-            ps.hit(RAY_NEE)[slot] = sphere_seed(sc, auxOrigin, auxL, withMask);
-            ps.hit(RAY_PROBE)[slot] = sphere_seed(sc, auxOrigin, auxC, withMask);
+            float4 sL = sphere_seed(sc, auxOrigin, auxL, withMask), sC = sphere_seed(sc, auxOrigin, auxC, withMask);
+            auxMask = 3u;
+            if (sc.emitMode) {
+                // Both are light queries: only "is the closest hit emissive, and at what distance" is read from them. With
+                // tE the nearest emissive primitive on the ray: none at all, or a sphere nearer than it, answers "not
+                // emissive" here and now (the record of a ray that hit nothing); otherwise the traversal carries tE in the
+                // record's w and stops at the first hit nearer than it.
+                const float tL = emitter_min_t(sc, auxOrigin, auxL, emitTests), tC = emitter_min_t(sc, auxOrigin, auxC, emitTests);
+                if (!(tL < RT_MISS_DST) || sL.x < tL) { sL.x = RT_MISS_DST; sL.y = __uint_as_float(RT_HIT_NONE); auxMask &= ~1u; }
+                else sL.w = tL;
+                if (!(tC < RT_MISS_DST) || sC.x < tC) { sC.x = RT_MISS_DST; sC.y = __uint_as_float(RT_HIT_NONE); auxMask &= ~2u; }
+                else sC.w = tC;
+            }
+            ps.hit(RAY_NEE)[slot] = sL;
+            ps.hit(RAY_PROBE)[slot] = sC;
         }
         ps.rayO()[slot] = mk4(ro, misW);
         ps.rayD()[slot] = mk4u(rd, state);
@@ -1113,7 +1202,7 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, ShadeArgs sa, FrameParams fp) {
-    __shared__ uint32_t s_cnt[RT_BLOCK / RT_WAVE][5];  // per wave: alive, aux, refRays, paths, segments
+    __shared__ uint32_t s_cnt[RT_BLOCK / RT_WAVE][6];  // per wave: alive, aux rays, refRays, paths, segments, emitter tests
     __shared__ uint32_t s_base[2];
     const uint32_t n = *sa.inCount;
     if (blockIdx.x * RT_BLOCK >= n) return;  // block-uniform
@@ -1121,48 +1210,46 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
     const bool live = gid < n;
 
     bool alive = false;    // path (or its successor sample) has a main ray for the next round
-    bool wantAux = false;  // and two probe rays
+    uint32_t auxMask = 0;  // ... bit 0: and a NEE ray, bit 1: and a cosine probe
     uint32_t slot = 0;
-    uint32_t refRays = 0, nPaths = 0;
+    uint32_t refRays = 0, nPaths = 0, emitTests = 0;
     if (live) {
         slot = sa.inActive[gid];
-        shade_path(sc, ps, fp, slot, alive, wantAux, refRays, nPaths);
+        shade_path(sc, ps, fp, slot, alive, auxMask, refRays, nPaths, emitTests);
     }
 
     // Queue compaction: ranks inside a wave from ballots, wave offsets through LDS, and ONE atomic
     // per block and queue (a single hot counter saturates near 90 atomics/us; per-wave atomics made
     // this kernel wait on them for half of its run time).
     const unsigned long long mAlive = __ballot(alive);
-    const unsigned long long mAux = __ballot(alive && wantAux);
-    const uint32_t nAlive = __popcll(mAlive), nAux = __popcll(mAux);
-    const uint32_t wRef = wave_sum_u32(refRays), wPaths = wave_sum_u32(nPaths), wSeg = wave_sum_u32(live ? 1u : 0u);
+    const unsigned long long mL = __ballot(alive && (auxMask & 1u)), mC = __ballot(alive && (auxMask & 2u));
+    const uint32_t nAlive = __popcll(mAlive), nL = __popcll(mL), nC = __popcll(mC);
+    const uint32_t wRef = wave_sum_u32(refRays), wPaths = wave_sum_u32(nPaths), wSeg = wave_sum_u32(live ? 1u : 0u), wEmit = wave_sum_u32(emitTests);
     const uint32_t wv = threadIdx.x / RT_WAVE;
     if (lane_id() == 0) {
-        s_cnt[wv][0] = nAlive; s_cnt[wv][1] = nAux; s_cnt[wv][2] = wRef; s_cnt[wv][3] = wPaths; s_cnt[wv][4] = wSeg;
+        s_cnt[wv][0] = nAlive; s_cnt[wv][1] = nL + nC; s_cnt[wv][2] = wRef; s_cnt[wv][3] = wPaths; s_cnt[wv][4] = wSeg; s_cnt[wv][5] = wEmit;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tA = 0, tX = 0, tRef = 0, tP = 0, tS = 0;
-        for (int w = 0; w < RT_BLOCK / RT_WAVE; w++) { tA += s_cnt[w][0]; tX += s_cnt[w][1]; tRef += s_cnt[w][2]; tP += s_cnt[w][3]; tS += s_cnt[w][4]; }
+        uint32_t tA = 0, tX = 0, tRef = 0, tP = 0, tS = 0, tE = 0;
+        for (int w = 0; w < RT_BLOCK / RT_WAVE; w++) { tA += s_cnt[w][0]; tX += s_cnt[w][1]; tRef += s_cnt[w][2]; tP += s_cnt[w][3]; tS += s_cnt[w][4]; tE += s_cnt[w][5]; }
         s_base[0] = tA ? atomicAdd(sa.outActiveCount, tA) : 0u;
-        s_base[1] = tA ? atomicAdd(sa.outRayCount, tA + 2u * tX) : 0u;
+        s_base[1] = tA ? atomicAdd(sa.outRayCount, tA + tX) : 0u;
         atomicAdd(&sa.counters->raysReference, (unsigned long long)tRef);
         atomicAdd(&sa.counters->paths, (unsigned long long)tP);
         atomicAdd(&sa.counters->segments, (unsigned long long)tS);
+        if (tE) atomicAdd(&sa.counters->emitterTests, (unsigned long long)tE);
     }
     __syncthreads();
     if (alive) {
         uint32_t baseA = s_base[0], baseR = s_base[1];
-        for (uint32_t w = 0; w < wv; w++) { baseA += s_cnt[w][0]; baseR += s_cnt[w][0] + 2u * s_cnt[w][1]; }
+        for (uint32_t w = 0; w < wv; w++) { baseA += s_cnt[w][0]; baseR += s_cnt[w][0] + s_cnt[w][1]; }
         const uint32_t rk = lanes_below(mAlive);
         sa.outActive[baseA + rk] = slot;
         // per wave: main rays first, then its NEE rays, then its cosine probes
         sa.outRays[baseR + rk] = (slot << 2) | RAY_MAIN;
-        if (wantAux) {
-            const uint32_t ra = lanes_below(mAux);
-            sa.outRays[baseR + nAlive + ra] = (slot << 2) | RAY_NEE;
-            sa.outRays[baseR + nAlive + nAux + ra] = (slot << 2) | RAY_PROBE;
-        }
+        if (auxMask & 1u) sa.outRays[baseR + nAlive + lanes_below(mL)] = (slot << 2) | RAY_NEE;
+        if (auxMask & 2u) sa.outRays[baseR + nAlive + nL + lanes_below(mC)] = (slot << 2) | RAY_PROBE;
     }
 }
 
@@ -1260,7 +1347,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
     const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
     const TracePwArgs ta{nullptr, nullptr, nullptr, fa.refill, 0u, fa.wSetup, fa.wLeaf, fa.fastLanes, fa.fastShare, nullptr, nullptr, fa.counters, nullptr, nullptr, fa.overflow};
     WaveTotals wt;
-    uint32_t refTot = 0, pathTot = 0, segTot = 0;
+    uint32_t refTot = 0, pathTot = 0, segTot = 0, emitTot = 0;
     const unsigned long long tKernelStart = fa.waveTimes ? wall_clock64() : 0ull;
     // scatter = g > 0: batchPixels is a multiple of g and a block is batchPixels / g chunks of g slots, nBatches apart
     const uint32_t nBatches = fa.scatter ? ((fp.nPixels + fa.scatter - 1) / fa.scatter + fa.batchPixels / fa.scatter - 1) / (fa.batchPixels / fa.scatter)
@@ -1272,7 +1359,8 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
     const uint32_t total = fa.scatter ? nBatches * fa.batchPixels : fp.nPixels;
     const uint32_t refillAt = min(max(fa.pixelRefill, 1u), fa.batchPixels);
     uint32_t slot = 0;
-    bool valid = false, alive = false, wantAux = false, exhausted = false;
+    bool valid = false, alive = false, exhausted = false;
+    uint32_t auxMask = 0;  // bit 0: the pixel's path has a NEE ray in flight, bit 1: a cosine probe
     for (;;) {
         const bool mine = lane_id() < fa.batchPixels && !alive;
         const unsigned long long mF = __ballot(mine);
@@ -1300,7 +1388,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
                 }
                 valid = a < total && ns < fp.nPixels;
                 slot = ns;
-                wantAux = false;
+                auxMask = 0;
                 if (valid) {
                     init_path(*sq, ps, *fq, slot);
                     alive = fp.samples > 0;
@@ -1312,17 +1400,14 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
             if (exhausted) break;
             continue;
         }
-        const unsigned long long mX = __ballot(alive && wantAux);
-        const uint32_t nA = __popcll(mA), nX = __popcll(mX);
+        const unsigned long long mL = __ballot(alive && (auxMask & 1u)), mC = __ballot(alive && (auxMask & 2u));
+        const uint32_t nA = __popcll(mA), nL = __popcll(mL), nC = __popcll(mC);
         if (alive) {
             list[lanes_below(mA)] = (slot << 2) | RAY_MAIN;
-            if (wantAux) {
-                const uint32_t ra = lanes_below(mX);
-                list[nA + ra] = (slot << 2) | RAY_NEE;
-                list[nA + nX + ra] = (slot << 2) | RAY_PROBE;
-            }
+            if (auxMask & 1u) list[nA + lanes_below(mL)] = (slot << 2) | RAY_NEE;
+            if (auxMask & 2u) list[nA + nL + lanes_below(mC)] = (slot << 2) | RAY_PROBE;
         }
-        const uint32_t nRays = nA + 2u * nX;
+        const uint32_t nRays = nA + nL + nC;
         __threadfence_block();  // the rays written by shade_path / init_path are read by other lanes of this wave
         trace_wave<STACK, OVF, PIX, false, true, CULL>(sc, ps, ta, stack, ovf, ovfStride, list, nRays, wt);
         __threadfence_block();  // ... and so are the hit records
@@ -1332,26 +1417,26 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
             const FusedKernArgs* kq = opaque_kernarg<FusedKernArgs>();
             const FrameParams* fq = &kq->fp;
             const DevScene* sq = &kq->sc;
-            wantAux = false;
-            shade_path(*sq, ps, *fq, slot, nowAlive, wantAux, refRays, nPaths, false);
+            shade_path(*sq, ps, *fq, slot, nowAlive, auxMask, refRays, nPaths, emitTot, false);
             segTot++;
             if (CULL && nowAlive && nBox) {
                 // the new rays' object masks (sphere_seed), here rather than inside shade_path: its registers are spilling already
                 float4 sd = ps.hit(RAY_MAIN)[slot];
                 sd.z = __uint_as_float(reach_mask_from(s_box, nBox, f4xyz(ps.rayO()[slot]), f4xyz(ps.rayD()[slot]), sc.cullOriginLimit));
                 ps.hit(RAY_MAIN)[slot] = sd;
-                if (wantAux) {
-                    const rt_vec3 ao = f4xyz(ps.auxO()[slot]);
+                if (auxMask & 1u) {
                     sd = ps.hit(RAY_NEE)[slot];
-                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, ao, f4xyz(ps.auxDL()[slot]), sc.cullOriginLimit));
+                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, f4xyz(ps.auxO()[slot]), f4xyz(ps.auxDL()[slot]), sc.cullOriginLimit));
                     ps.hit(RAY_NEE)[slot] = sd;
+                }
+                if (auxMask & 2u) {
                     sd = ps.hit(RAY_PROBE)[slot];
-                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, ao, f4xyz(ps.auxDC()[slot]), sc.cullOriginLimit));
+                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, f4xyz(ps.auxO()[slot]), f4xyz(ps.auxDC()[slot]), sc.cullOriginLimit));
                     ps.hit(RAY_PROBE)[slot] = sd;
                 }
             }
             alive = nowAlive;
-            wantAux = wantAux && nowAlive;
+            auxMask = nowAlive ? auxMask : 0u;
             refTot += refRays;
             pathTot += nPaths;
         }
@@ -1368,8 +1453,9 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
     }
     unsigned long long wb = wave_sum_u64(wt.totBox), wtri = wave_sum_u64(wt.totTri);
     uint32_t wr = wave_sum_u32(wt.totRays), wh = wave_sum_u32(wt.totHits);
-    uint32_t wRef = wave_sum_u32(refTot), wP = wave_sum_u32(pathTot), wS = wave_sum_u32(segTot);
+    uint32_t wRef = wave_sum_u32(refTot), wP = wave_sum_u32(pathTot), wS = wave_sum_u32(segTot), wE = wave_sum_u32(emitTot);
     if (lane_id() == 0 && (wr | wP | wS)) {
+        if (wE) atomicAdd(&fa.counters->emitterTests, (unsigned long long)wE);
         atomicAdd(&fa.counters->boxTests, wb);
         atomicAdd(&fa.counters->triTests, wtri);
         atomicAdd(&fa.counters->raysTraced, (unsigned long long)wr);

@@ -25,7 +25,7 @@ from ray_tracer_amd import engine, scenes
 pytestmark = pytest.mark.gpu
 
 MODES = [("multikernel", 0, 0), ("fused", 1, 64), ("fused-refill", 1, 8)]
-KEYS = ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments")
+KEYS = ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments", "emitterTests")
 
 # name -> (scene factory key, width, height, triangles the stand-in must have, rows of the frame that are compared)
 CONFIGS = {
@@ -90,7 +90,7 @@ def test_config_at_full_size_on_sampled_rows(renderer, config):
         tile = dict(row0=H // 16 + 3, rowStride=H // 8, nRows=8)
         rows = slice(tile["row0"], None, tile["rowStride"])
         ref, rc = pyoracle.render(s, pc, W, H, **tile)
-        assert rc["stackOverflow"] == 0
+        assert rc["stackOverflow"] == 0 and rc["lightQueryMismatch"] == 0
         _set_mode(r, -1, 0)
         full = r.render(pc, W, H)             # the whole frame, as bench.py dispatches it
         assert full.shape == (H, W, 4)

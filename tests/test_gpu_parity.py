@@ -44,9 +44,10 @@ def _check(img, cnt, ref, rc):
     assert np.allclose(img, ref, rtol=RTOL, atol=1e-7, equal_nan=True), \
         f"{int((~np.isclose(img, ref, rtol=RTOL, atol=1e-7)).sum())} values beyond 1e-4"
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), "pixels not bit-identical"
-    for k in ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments"):
+    for k in ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments", "emitterTests"):
         assert cnt[k] == rc[k], f"counter {k}: gpu {cnt[k]} oracle {rc[k]}"
     assert rc["stackOverflow"] == 0
+    assert rc["lightQueryMismatch"] == 0, "a light query answered from the emitter list disagrees with the shader's closest hit"
 
 
 def test_device_selftest(renderer):
@@ -696,3 +697,43 @@ def test_srgb8_readback_against_numpy(renderer):
     assert diff.max() <= 1
     assert (diff == 0).mean() > 0.995
     assert got[..., :3].max() > 200 and got[..., :3].min() < 30 and (got[..., 3] == 255).all()
+
+
+def test_light_queries_on_and_off(renderer):
+    """The NEE ray and the cosine probe answered from the emitter list (default) or traversed in full (light_queries 0):
+    the same pixels, and in either mode the executed-work counters the oracle predicts for that mode. Scenes: the Cornell
+    light only; an emissive sphere and a second emissive quad; an emissive mesh beyond RT_EMIT_MAX_TRIS (shortcut off)."""
+    import os
+    scn = []
+    scn.append(("cornell", cornell_scene(True)))
+    s = cornell_scene(True)
+    glow = s.add_material(engine.default_material(albedo=(0.1, 0.1, 0.1), emissionColor=(0.3, 0.6, 1.0), emissionStrength=1.2))
+    s.set_sphere(3, (-0.6, -0.9, 0.4), 0.2, glow)
+    quad = np.array([[[-0.2, -1.499, 0.5], [0.2, -1.499, 0.5], [0.2, -1.499, 0.8]], [[-0.2, -1.499, 0.5], [0.2, -1.499, 0.8], [-0.2, -1.499, 0.8]]], np.float32)
+    nq = np.zeros_like(quad); nq[..., 1] = 1
+    s.add_mesh("second_light", quad, nq, engine.placement(rotation=(0, 15, 0)), glow)
+    scn.append(("sphere+quad", s))
+    s = cornell_scene(False)
+    glow = s.add_material(engine.default_material(albedo=(0.9, 0.6, 0.2), emissionColor=(1.0, 0.5, 0.1), emissionStrength=3.0))
+    s.read_obj(os.path.join(engine.ASSET_DIR, "bunny.obj"), engine.placement(position=(0.0, 0.4, 0.0), scale=0.5), glow)
+    scn.append(("emissive-bunny", s))
+    W, H = 96, 72
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3)
+    try:
+        for name, s in scn:
+            frames = []
+            for on in (1, 0):
+                renderer.set_tuning("light_queries", on)
+                pyoracle.lib().oracle_set_light_queries(on)
+                img, cnt, ref, rc = _render_both(renderer, s, pc, W, H)
+                _check(img, cnt, ref, rc)
+                frames.append((img, cnt))
+            assert np.array_equal(frames[0][0].view(np.uint32), frames[1][0].view(np.uint32)), name
+            if name != "emissive-bunny":
+                assert frames[0][1]["raysTraced"] < 0.8 * frames[1][1]["raysTraced"], "the shortcut must save light queries"
+                assert frames[0][1]["emitterTests"] > 0
+            else:
+                assert frames[0][1]["emitterTests"] == 0 and frames[0][1]["raysTraced"] == frames[1][1]["raysTraced"]
+    finally:
+        renderer.set_tuning("light_queries", 1)
+        pyoracle.lib().oracle_set_light_queries(1)

@@ -1,0 +1,98 @@
+"""The light-query shortcut (rt_kernels.hip.h: emitter_min_t; oracle: executed_light_query) against the shader's own closest
+hit, on the CPU. For every NEE ray and cosine probe the oracle evaluates both — the full closest-hit query of
+raytrace.comp:443-453 and the pipeline's way (emissive primitives tested directly, traversal stopped at the first hit that
+answers the question) — and counts the queries whose answers differ. That count must be zero, on scenes chosen to stress
+it: emissive spheres, a second emitter coplanar with the ceiling, emitters behind glass, degenerate and coincident
+triangles, random scenes. (The GPU tests then check that the device executes exactly the work the oracle predicts.)"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from ray_tracer_amd import engine, scenes
+
+from util import cornell_scene, model_scene
+
+
+def _scenes():
+    yield "cornell", cornell_scene(True), {}
+    s = cornell_scene(True)
+    glow = s.add_material(engine.default_material(albedo=(0.1, 0.1, 0.1), emissionColor=(0.3, 0.6, 1.0), emissionStrength=1.2))
+    s.set_sphere(3, (-0.6, -0.9, 0.4), 0.2, glow)
+    s.set_sphere(4, (0.1, -1.3, 0.0), 0.25, 5)       # glass right under the ceiling light
+    quad = np.array([[[-0.2, -1.5, 0.5], [0.2, -1.5, 0.5], [0.2, -1.5, 0.8]], [[-0.2, -1.5, 0.5], [0.2, -1.5, 0.8], [-0.2, -1.5, 0.8]]], np.float32)
+    nq = np.zeros_like(quad); nq[..., 1] = 1
+    s.add_mesh("coplanar_light", quad, nq, engine.placement(), glow)   # in the plane of the ceiling: equal distances
+    yield "emitters", s, dict(bounceLimit=6)
+    s = model_scene("bunny.obj", material=0, spheres=True)
+    yield "bunny", s, {}
+    s, _ = scenes.sponza(0, ntris=20000)
+    yield "sponza20k", s, dict(cam=scenes.sponza_camera)
+    # the light's own material on a second copy of light2.obj, overlapping the first (coincident emissive triangles)
+    s = cornell_scene(False)
+    s.read_obj(os.path.join(engine.ASSET_DIR, "light2.obj"), engine.placement(position=(0, -1.5, 0), frontOnly=False), 3)
+    s.read_obj(os.path.join(engine.ASSET_DIR, "cube.obj"), engine.placement(position=(0, -1.2, 0), scale=0.2), 0)   # an occluder below the light
+    yield "coincident", s, {}
+
+
+@pytest.mark.parametrize("name,scene,kw", list(_scenes()), ids=lambda v: v if isinstance(v, str) else "")
+def test_shortcut_answers_equal_the_shaders(name, scene, kw):
+    kw = dict(kw)
+    cam = kw.pop("cam", engine.push_constants)
+    W, H = 120, 90
+    pc = cam(W, H, singleRender=1, sampleLimit=3, **kw)
+    out = {}
+    try:
+        for on in (1, 0):
+            pyoracle.lib().oracle_set_light_queries(on)
+            out[on] = pyoracle.render(scene, pc, W, H)
+    finally:
+        pyoracle.lib().oracle_set_light_queries(1)
+    (img1, c1), (img0, c0) = out[1], out[0]
+    assert np.array_equal(img1.view(np.uint32), img0.view(np.uint32))      # pixels never depend on the counters' definition
+    assert c1["lightQueryMismatch"] == 0 and c0["lightQueryMismatch"] == 0
+    assert c1["raysReference"] == c0["raysReference"] and c1["boxTestsReference"] == c0["boxTestsReference"]
+    assert c1["raysTraced"] < c0["raysTraced"] and c1["boxTests"] <= c0["boxTests"]
+    assert c0["emitterTests"] == 0 and c1["emitterTests"] > 0
+
+
+def test_shortcut_is_off_when_it_would_not_be_exact_or_cheap():
+    """A material whose emissionColor * emissionStrength is not finite (0 * inf = NaN would reach the pixel), and an emissive
+    mesh with more triangles than RT_EMIT_MAX_TRIS: every light query is traversed in full."""
+    W, H = 48, 36
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2)
+    s = cornell_scene(True)
+    s.add_material(engine.default_material(emissionColor=(np.inf, 0, 0), emissionStrength=0.0))
+    _, c = pyoracle.render(s, pc, W, H)
+    assert c["emitterTests"] == 0
+    s = cornell_scene(False)
+    glow = s.add_material(engine.default_material(emissionColor=(1, 1, 1), emissionStrength=1.0))
+    s.read_obj(os.path.join(engine.ASSET_DIR, "bunny.obj"), engine.placement(position=(0.0, 0.4, 0.0), scale=0.5), glow)
+    _, c = pyoracle.render(s, pc, W, H)
+    assert c["emitterTests"] == 0 and c["lightQueryMismatch"] == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_emitters(seed):
+    rng = np.random.default_rng(4000 + seed)
+    s = cornell_scene(False)
+    mats = [0, 1, 2, 4, 5]
+    for _ in range(2):
+        mats.append(s.add_material(engine.default_material(albedo=tuple(rng.random(3)), emissionColor=tuple(rng.random(3)),
+                                                            emissionStrength=float(rng.random() * 3 + 0.1))))
+    for k in range(int(rng.integers(2, 6))):
+        n = int(rng.integers(1, 9))
+        tri = rng.uniform(-0.8, 0.8, (n, 3, 3)).astype(np.float32)
+        tri[:, :, 1] -= 0.5
+        tri[:, 1:, :] = tri[:, :1, :] + rng.uniform(-0.35, 0.35, (n, 2, 3)).astype(np.float32)
+        nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-9)
+        pl = engine.placement(rotation=tuple(rng.uniform(-40, 40, 3)), scale=tuple(rng.uniform(0.6, 1.2, 3))) if rng.random() < 0.5 else engine.placement()
+        s.add_mesh(f"e{seed}_{k}", tri, np.repeat(nrm[:, None, :], 3, axis=1).astype(np.float32), pl, int(rng.choice(mats)))
+    for i in range(int(rng.integers(0, 5))):
+        s.set_sphere(i, tuple(rng.uniform(-0.7, 0.7, 3)), float(rng.uniform(0.05, 0.3)), int(rng.choice(mats)))
+    W, H = 80, 60
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2, bounceLimit=int(rng.integers(2, 9)), environmentOn=bool(seed % 2))
+    _, c = pyoracle.render(s, pc, W, H)
+    assert c["lightQueryMismatch"] == 0
