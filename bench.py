@@ -52,6 +52,10 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="send a one-rank job through the process group, gather and reductions too (RCCL smoke test on a one-GPU box)")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole frame alone and compares it with the gathered one")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="steps (= progressive frames) a rank submits at once through rt_render_frames; 0 = as many as give the rank "
+                         "a full frame's worth of pixels (1 on one GPU, N on N GPUs: a 1/N tile has too few pixels to fill a GPU, "
+                         "because a pixel's samples are serial), 1 = every step its own dispatch and its own gather")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,17 +110,25 @@ def main():
     sendbuf = torch.zeros_like(strip) if multi else None
     pending = [False]
 
-    def launch(i):
+    # Steps are progressive frames: independent until they are blended in order. A rank may therefore submit a group of
+    # them at once (rt_render_frames: their pixels share a launch, the blends follow in frame order — the same bits as
+    # one dispatch per step); the strips are gathered once per group.
+    fif = args.frames_in_flight if args.frames_in_flight > 0 else world
+
+    def launch(i, n):
         pc.frameCount = i
-        r.render(pc, W, H, row0=rank, rowStride=world, nRows=len(rows), out_ptr=strip.data_ptr(), sync=False)
+        if n == 1:
+            r.render(pc, W, H, row0=rank, rowStride=world, nRows=len(rows), out_ptr=strip.data_ptr(), sync=False)
+        else:
+            r.render_frames(pc, W, H, n, row0=rank, rowStride=world, nRows=len(rows), out_ptr=strip.data_ptr(), sync=False)
 
     def finish_previous():
         if pending[0]:
             tiling.gather_frame(sendbuf.cpu() if rehearsal else sendbuf, frame, H, world, rank, force_collective=multi)
             pending[0] = False
 
-    def step(i):
-        launch(i)
+    def step(i, n=1):
+        launch(i, n)
         if multi:
             finish_previous()      # gather of step i-1 overlaps the render of step i
         r.sync()
@@ -133,14 +145,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    def run(first, count):
+        i = first
+        while i < first + count:
+            n = min(fif, first + count - i)
+            step(i, n)
+            i += n
+
+    run(0, args.warmup)
     r.reset_counters()
     r.set_profiling(not args.no_profile)
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    run(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
     trace_ms, trace_launches = r.trace_time_ms()
@@ -171,8 +188,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} ({label}), {W}x{H}, {args.spp} spp/step, bounceLimit 8, "
-                                   f"rows interleaved over {world} GPU(s)" + (", RCCL gather per step" if world > 1 else ""),
-                       "scene": args.scene, "assets": label, "width": W, "height": H, "spp_per_step": args.spp,
+                                   f"rows interleaved over {world} GPU(s)" + (f", {fif} steps in flight per rank, one RCCL gather per group" if world > 1 else ""),
+                       "scene": args.scene, "assets": label, "width": W, "height": H, "spp_per_step": args.spp, "frames_in_flight": fif,
                        "pipeline": ["multi-kernel (k_trace_pw + k_shade per round)", "fused (k_render_fused)"][r.last_pipeline()]},
             "unique_mrays_per_s": tot["raysTraced"] / dt / 1e6,
             "spp_per_s": tot["paths"] / (W * H) / dt,
@@ -180,18 +197,33 @@ def main():
             "box_tests_per_ray": tot["boxTests"] / max(tot["raysTraced"], 1), "tri_tests_per_ray": tot["triTests"] / max(tot["raysTraced"], 1),
             "roofline": {"bound": "hbm", "kernel": ["k_trace_pw", "k_render_fused (traversal + shading in one kernel)"][r.last_pipeline()], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
+                         "achieved_is": "algorithmic bytes (32 B per box test + 36 B per triangle test + 100 B per hit, SURVEY 8d) per launch / launch time: a cache-served rate, see hbm_counter_frac for what reaches the fabric",
                          "algorithmic_bytes_per_launch": alg_bytes / max(sum_launches, 1.0),
                          "avg_launch_ms": sum_trace_ms / max(sum_launches, 1.0), "launches": sum_launches,
                          "trace_share_of_step": (sum_trace_ms / world) / (dt * 1e3)},
         }
-        # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes of this same command
-        # (tools/pmc_traffic.py -> profiles/); PMC counters cannot be read from inside the process
-        tkern = ["k_trace", "k_render_fused"][r.last_pipeline()]
-        tfile = os.path.join(ROOT, "profiles", f"traffic_{tkern}_{args.scene}_{W}x{H}_{args.spp}spp.json")
-        if world == 1 and os.path.exists(tfile):
-            with open(tfile) as f:
-                out["roofline"]["traffic"] = json.load(f)["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = os.path.relpath(tfile, ROOT)
+        # What the hardware counters say about the same kernel: separate rocprofv3 --pmc passes of this very command
+        # (tools/profile_round.sh -> profiles/), since PMC counters cannot be read from inside the process. The file is
+        # stamped with a hash of the kernel sources; a stamp that no longer matches the tree is flagged, not hidden.
+        tkern = ["k_trace_pw", "k_render_fused"][r.last_pipeline()]
+        cfile = os.path.join(ROOT, "profiles", f"counters_{tkern}_{args.scene}_{W}x{H}_{args.spp}spp.json")
+        rf = out["roofline"]
+        if world == 1 and os.path.exists(cfile):
+            with open(cfile) as f:
+                pm = json.load(f)
+            launch_s = rf["avg_launch_ms"] * 1e-3
+            rf["traffic"] = pm.get("traffic_bytes_per_launch")
+            rf["counters_source"] = os.path.relpath(cfile, ROOT)
+            rf["counters_stale"] = pm.get("source_sha") != kernel_source_sha()
+            if rf["traffic"] and launch_s > 0:
+                rf["hbm_counter_gbps"] = rf["traffic"] / launch_s / 1e9
+                rf["hbm_counter_frac"] = rf["hbm_counter_gbps"] / 8000.0
+            for k in ("ta_busy_frac", "valu_issue_frac", "active_lane_frac", "wave_waiting_frac", "l1_lookups_per_ray",
+                      "effective_clock_ghz"):
+                if k in pm:
+                    rf[k] = pm[k]
+            rf["bound_by_counters"] = ("vector memory pipeline (TA busy) and VALU issue together, not HBM: the algorithmic bytes are mostly "
+                                       "served by L1 / L2 (traffic << algorithmic), see DESIGN.md section 6")
         if world == 1:
             # the nominal peak and a streaming copy measured on this very box (1 GiB, read + write), both quoted
             out["roofline"]["measured_copy_gbps"] = r.copy_bandwidth_gbps(1 << 30, 5)
@@ -227,6 +259,16 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_source_sha():
+    """Hash of the sources the traversal kernels are built from (the stamp tools/pmc_roofline.py puts into profiles/)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ray_tracer_amd/csrc/rt_kernels.hip.h", "ray_tracer_amd/csrc/rt_device.hip", "include/rt_det_math.h"):
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(scene, pc, W, H, args):

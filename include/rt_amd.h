@@ -279,7 +279,18 @@ int  rt_update_objects(rt_ctx* ctx, const RenderObject* o, uint32_t n);
  * Asynchronous on the ctx stream; rt_sync waits. */
 int  rt_render(rt_ctx* ctx, const PushConstants* pc, uint32_t width, uint32_t height,
                uint32_t row0, uint32_t rowStride, uint32_t nRows, float* d_rgba);
+/* nFrames consecutive progressive dispatches of the same tile — the same pixels, bit for bit, as nFrames calls of rt_render
+ * with frameCount = pc->frameCount, pc->frameCount + 1, ... (the reference's frame loop, src/vk_engine.cpp:1782-1814, runs them
+ * one after the other and waits for each). Frames are independent until they are blended (each has its own RNG seeds,
+ * raytrace.comp:562-564), so where one frame of the tile leaves the GPU short of pixels — a 1/8-height tile of a 1080p frame
+ * has fewer pixels than the GPU has resident lanes, and a pixel's samples are serial — their pixels share one launch and
+ * the frames are blended into d_rgba in order afterwards. Not for the debug heat maps (rendered frame by frame then).
+ * "frames_per_launch" (rt_set_tuning) caps the frames per launch; 0 = as many as fit. */
+int  rt_render_frames(rt_ctx* ctx, const PushConstants* pc, uint32_t width, uint32_t height,
+                      uint32_t row0, uint32_t rowStride, uint32_t nRows, uint32_t nFrames, float* d_rgba);
 int  rt_sync(rt_ctx* ctx);
+/* forget the ctx's own framebuffer: the next rt_render(…, NULL) starts a new progressive history from a zeroed image */
+int  rt_clear_framebuffer(rt_ctx* ctx);
 /* copies the ctx's own framebuffer of the last rt_render(…, NULL) to host */
 int  rt_read_rgba_f32(rt_ctx* ctx, float* hostOut, size_t nFloats);
 /* 8-bit sRGB-encoded RGBA of the same framebuffer (the reference's display format) */

@@ -127,7 +127,9 @@ SYMBOLS = {
     "rt_update_spheres": (C.c_int, [_vp, _P(Sphere), C.c_uint32]),
     "rt_update_objects": (C.c_int, [_vp, _P(RenderObject), C.c_uint32]),
     "rt_render": (C.c_int, [_vp, _P(PushConstants), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
+    "rt_render_frames": (C.c_int, [_vp, _P(PushConstants), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "rt_sync": (C.c_int, [_vp]),
+    "rt_clear_framebuffer": (C.c_int, [_vp]),
     "rt_read_rgba_f32": (C.c_int, [_vp, _P(C.c_float), C.c_size_t]),
     "rt_read_rgba8_srgb": (C.c_int, [_vp, _P(C.c_uint8), C.c_size_t]),
     "rt_trace_rays": (C.c_int, [_vp, C.c_uint32, _P(C.c_float), _P(C.c_float), _P(RtHit)]),

@@ -43,6 +43,7 @@ struct rt_ctx {
     // host copies of what the emitter list is derived from (rebuild_emitters)
     std::vector<RayMaterial> hostMats;
     std::vector<uint32_t> hostSphereMat, hostObjMat, hostObjRoot;
+    int framesPerLaunch = 0; // rt_render_frames: most frames of a tile rendered by one launch (0 = as many as fit)
     int lightQueries = 1;   // rt_set_tuning("light_queries", 0): trace every NEE ray and cosine probe in full
     uint32_t maxLeafDepth = 0;
     std::vector<uint32_t> nodeRemap;          // reference node index -> device node index
@@ -244,23 +245,24 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_render_fused<STACK, OVF, false, CULL>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
     }
     const uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
+    const uint32_t nSlots = fp.nFrames > 1u ? ((fp.nPixels + 63u) / 64u) * 64u * fp.nFrames : fp.nPixels;  // rt_render_frames: frames are more slots of the same tile (rt_kernels.hip.h: frame_slot)
     // Pixels are replaced as they finish when rays are long (Sponza -7 %, its 1/2 and 1/4 tiles -8 % and -11 %: the wave no
     // longer drains to its slowest pixel once per block) and when a wave gets fewer than five blocks (Cornell + bunny /
     // + dragon, rank 0's rows of 2 GPUs -3 %, of 4 GPUs -13 %); with short rays and many blocks per wave a block at a
     // time is 4-7 % faster (the full 1080p frame of Cornell, + bunny, + dragon)
-    const bool fewBlocks = ((uint64_t)fp.nPixels + RT_WAVE - 1) / RT_WAVE < 5ull * resident * (RT_BLOCK / RT_WAVE);
+    const bool fewBlocks = ((uint64_t)nSlots + RT_WAVE - 1) / RT_WAVE < 5ull * resident * (RT_BLOCK / RT_WAVE);
     const uint32_t pixelRefill = c->pixelRefill > 0 ? (uint32_t)c->pixelRefill
                                : ((c->boxPerRay >= (double)c->fusedBelowBoxTests || fewBlocks) ? 8u : (uint32_t)RT_WAVE);
     // a wave that replaces its pixels one by one evens out by itself as soon as there is more than one block per wave
     const uint32_t evenBelow = pixelRefill < RT_WAVE ? 1u : 2u;
-    uint32_t batchPixels = fused_batch_pixels(c, fp.nPixels, resident * (RT_BLOCK / RT_WAVE), evenBelow);
+    uint32_t batchPixels = fused_batch_pixels(c, nSlots, resident * (RT_BLOCK / RT_WAVE), evenBelow);
     // With one or two blocks per wave (one, when pixels are replaced as they finish) the tile is done when the most expensive block is: blocks made of 4-slot chunks from
     // all over the tile cost about the same (-6 % on a 1/8-height 1080p tile); with more blocks per wave the dynamic
     // hand-out balances by itself and neighbouring pixels (shared cache lines, coherent rays) are 3-8 % faster.
     const uint32_t wavesResident = resident * (RT_BLOCK / RT_WAVE);
-    const uint32_t g = c->scatter >= 0 ? (uint32_t)c->scatter : ((((uint64_t)fp.nPixels + RT_WAVE - 1) / RT_WAVE <= (uint64_t)evenBelow * wavesResident) ? 4u : 0u);
+    const uint32_t g = fp.nFrames > 1u ? 0u : c->scatter >= 0 ? (uint32_t)c->scatter : ((((uint64_t)nSlots + RT_WAVE - 1) / RT_WAVE <= (uint64_t)evenBelow * wavesResident) ? 4u : 0u);
     if (g) batchPixels = std::min((uint32_t)RT_WAVE, (batchPixels + g - 1) / g * g);
-    const uint32_t nBatches = g ? ((fp.nPixels + g - 1) / g + batchPixels / g - 1) / (batchPixels / g) : (fp.nPixels + batchPixels - 1) / batchPixels;
+    const uint32_t nBatches = g ? ((nSlots + g - 1) / g + batchPixels / g - 1) / (batchPixels / g) : (nSlots + batchPixels - 1) / batchPixels;
     const uint32_t blocks = std::max(1u, std::min((nBatches + (RT_BLOCK / RT_WAVE) - 1) / (RT_BLOCK / RT_WAVE), resident));
     uint32_t* overflow = nullptr;
     if (OVF) {
@@ -375,6 +377,8 @@ int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     c->traceLaunchesTotal++;
     return 0;
 }
+
+void poll_ray_cost(rt_ctx* c);
 
 // sum finished event pairs; the stream must be idle
 int harvest_events(rt_ctx* c) {
@@ -851,8 +855,12 @@ int probe_ray_cost(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t 
 
 extern "C" {
 
-int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t height, uint32_t row0, uint32_t rowStride,
-              uint32_t nRows, float* d_rgba) {
+}  // extern "C"
+
+namespace {
+// rt_render (nFrames = 1) and rt_render_frames
+int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t height, uint32_t row0, uint32_t rowStride,
+                uint32_t nRows, uint32_t nFrames, float* d_rgba) {
     if (!c || !pc) return -1;
     if (width == 0 || height == 0 || rowStride == 0) return c->fail("rt_render: bad image geometry");
     if (nRows && (uint64_t)row0 + (uint64_t)(nRows - 1) * rowStride >= height) return c->fail("rt_render: rows exceed the image");
@@ -861,12 +869,12 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     if (td.sphereCount > c->sc.sphereCount) return c->fail("rayTraceParams.sphereCount exceeds the uploaded spheres");
     if (td.objectCount > c->sc.objectCount) return c->fail("rayTraceParams.objectCount exceeds the uploaded objects");
     const uint64_t np64 = (uint64_t)nRows * width;
-    if (np64 >= (1ull << 30)) return c->fail("tile too large (slot ids are 30 bits)");
+    if ((np64 + 63) / 64 * 64 * nFrames >= (1ull << 30)) return c->fail("tile too large (slot ids are 30 bits)");
     const uint32_t nPixels = (uint32_t)np64;
     RT_HIP(c, hipSetDevice(c->device));
     if (nPixels == 0) return 0;
 
-    int rc = ensure_state(c, nPixels);
+    int rc = ensure_state(c, nFrames > 1u ? (nPixels + 63u) / 64u * 64u * nFrames : nPixels);
     if (rc) return rc;
     float4* fb = (float4*)d_rgba;
     if (!fb) {
@@ -895,6 +903,7 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     fp.bounceLimit = td.bounceLimit;
     fp.progressive = td.progressive;
     fp.frameCount = pc->frameCount;
+    fp.nFrames = nFrames;
     fp.debug = td.debug;
     fp.boxCap = td.boxCap;
     fp.triCap = td.triangleCap;
@@ -932,8 +941,13 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     double sizeLimit = (double)c->fusedBelowPixels;
     if (c->boxPerRay > 160.0) sizeLimit = std::max(800000.0, sizeLimit - (c->boxPerRay - 160.0) * 75000.0);
     c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (((double)nPixels < sizeLimit || shortRays) ? 1 : 0);
+    if (nFrames > 1u) c->lastPipeline = 1;  // several frames in one launch exist in the fused kernel only (rt_render_frames decides)
     if (c->lastPipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch
         rc = launch_fused(c, fp, fb);
+        if (!rc && nFrames > 1u) {
+            hipLaunchKernelGGL(k_blend_frames, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->ps, fp, fb);
+            rc = c->hip(hipGetLastError(), "k_blend_frames");
+        }
         if (!rc) request_ray_cost(c);
         return rc;
     }
@@ -979,6 +993,51 @@ int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t heigh
     hipLaunchKernelGGL(k_resolve, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->ps, fp, fb);
     RT_HIP(c, hipGetLastError());
     request_ray_cost(c);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int rt_render(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t height, uint32_t row0, uint32_t rowStride,
+              uint32_t nRows, float* d_rgba) {
+    return render_impl(c, pc, width, height, row0, rowStride, nRows, 1u, d_rgba);
+}
+
+int rt_render_frames(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t height, uint32_t row0, uint32_t rowStride,
+                     uint32_t nRows, uint32_t nFrames, float* d_rgba) {
+    if (!c || !pc) return -1;
+    if (nFrames == 0) return 0;
+    // One launch for all the frames when the fused pipeline would render each of them anyway (forced, or the automatic
+    // choice for one frame of this tile: small tiles and short rays, the cases that leave a GPU short of pixels) and the
+    // frames are ordinary ones (no heat maps: those read per-pixel counters at resolve time). Otherwise frame by frame.
+    const uint64_t np = (uint64_t)nRows * width;
+    const bool shortRays = c->boxPerRay >= 0.0 && c->boxPerRay < (double)c->fusedBelowBoxTests;
+    double sizeLimit = (double)c->fusedBelowPixels;
+    if (c->boxPerRay > 160.0) sizeLimit = std::max(800000.0, sizeLimit - (c->boxPerRay - 160.0) * 75000.0);
+    const bool fusedOne = c->pipeline == 1 || (c->pipeline < 0 && ((double)np < sizeLimit || shortRays));
+    uint32_t per = 1;  // frames per launch
+    if (fusedOne && nFrames > 1u && pc->rayTraceParams.debug < 0 && np > 0) {
+        // as many frames per launch as keep the launch below the size at which one frame would leave the fused pipeline,
+        // and within the 30-bit slot ids
+        const uint64_t cap = std::min<uint64_t>((uint64_t)std::max(sizeLimit, (double)np), (1ull << 30) - 1);
+        per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nFrames, cap / ((np + 63) / 64 * 64)));
+        if (c->framesPerLaunch > 0) per = std::min(per, (uint32_t)c->framesPerLaunch);
+    }
+    PushConstants p = *pc;
+    for (uint32_t f = 0; f < nFrames; f += per) {
+        const uint32_t n = std::min(per, nFrames - f);
+        p.frameCount = pc->frameCount + f;
+        int rc = render_impl(c, &p, width, height, row0, rowStride, nRows, n, d_rgba);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int rt_clear_framebuffer(rt_ctx* c) {
+    if (!c) return -1;
+    c->fbPixels = 0;  // the next rt_render(..., NULL) starts from a zeroed image
+    c->fbValid = false;
     return 0;
 }
 
@@ -1082,6 +1141,8 @@ int rt_get_counters(rt_ctx* c, RtCounters* out) {
 int rt_reset_counters(rt_ctx* c) {
     if (!c) return -1;
     RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    poll_ray_cost(c);  // a snapshot of the last dispatch's counters has arrived by now: what it says about the scene's rays is kept
     RT_HIP(c, hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 128, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->snapPending = false;
@@ -1113,6 +1174,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     std::string k(key);
     if (k == "pipeline") { if (value < -1 || value > 1) return c->fail("pipeline: -1 (auto), 0 or 1"); c->pipeline = value; }
     else if (k == "probe") { c->probe = value ? 1 : 0; }
+    else if (k == "frames_per_launch") { if (value < 0) return c->fail("frames_per_launch >= 0"); c->framesPerLaunch = value; }
     else if (k == "light_queries") { c->lightQueries = value ? 1 : 0; int rc = rebuild_emitters(c); if (rc) return rc; }
     else if (k == "fused_below_box_tests") { if (value < 0) return c->fail("fused_below_box_tests >= 0"); c->fusedBelowBoxTests = (uint32_t)value; }
     else if (k == "fused_below_pixels") { if (value < 0) return c->fail("fused_below_pixels >= 0"); c->fusedBelowPixels = (uint32_t)value; }

@@ -127,6 +127,11 @@ struct FrameParams {
     uint32_t startingSeed;  // uint(random(frameCount) * 23892183)
     uint32_t samples, bounceLimit;
     uint32_t progressive, frameCount;
+    uint32_t nFrames;       // > 1: this launch renders that many consecutive progressive frames of the tile at once (rt_render_frames).
+                            // Slots then run over {64 tile slots} x {frames}: slot = (tile slot / 64) * 64 * nFrames + frame * 64 +
+                            // tile slot % 64 (frame_slot), so that the waves in flight work on one region of the tile in all its
+                            // frames (the frames' camera rays are identical: no jitter, raytrace.comp:541-557) rather than on the
+                            // whole tile of one frame; frame f has frameCount + f and its own startingSeed
     int32_t debug;
     uint32_t boxCap, triCap;
     EnvironmentData env;
@@ -950,7 +955,15 @@ __device__ __forceinline__ rt_vec3 primary_dir(const FrameParams& fp, uint32_t g
 // block, like the reference's 8x8 workgroups, raytrace.comp:4), so the rays of a
 // wave start out coherent; a remainder of fewer than 8 rows, or a width that is
 // not a multiple of 8, falls back to row-major order. `k` is the local row.
+// several frames per launch: which frame a slot belongs to, its slot in the tile, and back
+__device__ __forceinline__ uint32_t slot_frame(const FrameParams& fp, uint32_t slot) { return (slot >> 6) % fp.nFrames; }
+__device__ __forceinline__ uint32_t slot_in_tile(const FrameParams& fp, uint32_t slot) { return ((slot >> 6) / fp.nFrames << 6) | (slot & 63u); }
+__device__ __forceinline__ uint32_t frame_slot(const FrameParams& fp, uint32_t frame, uint32_t tileSlot) {
+    return ((tileSlot >> 6) * fp.nFrames + frame) * 64u + (tileSlot & 63u);
+}
+
 __device__ __forceinline__ void slot_to_pixel(const FrameParams& fp, uint32_t slot, uint32_t& gx, uint32_t& gy, uint32_t& k) {
+    if (fp.nFrames > 1u) slot = slot_in_tile(fp, slot);  // the same pixel in every frame of the launch
     const uint32_t tiledSlots = fp.tiled ? (fp.nRows & ~7u) * fp.width : 0u;
     if (slot < tiledSlots) {
         const uint32_t tile = slot >> 6, in = slot & 63u;
@@ -973,7 +986,12 @@ __device__ __forceinline__ void init_path(const DevScene& sc, const PathState& p
     slot_to_pixel(fp, slot, gx, gy, krow);
     ps.rayO()[slot] = make_float4(fp.camPos[0], fp.camPos[1], fp.camPos[2], 1.f);                          // misWeight = 1
     const rt_vec3 pd = primary_dir(fp, gx, gy);
-    ps.rayD()[slot] = mk4u(pd, gy * fp.width + gx + fp.startingSeed);                                   // RNG seed (:564)
+    uint32_t startingSeed = fp.startingSeed;
+    if (fp.nFrames > 1u) {  // frame f of the launch: uint(random(frameCount + f) * 23892183), as the host computes it for one frame
+        uint32_t lol = fp.frameCount + slot_frame(fp, slot);
+        startingSeed = (uint32_t)(rt_random(&lol) * 23892183.f);
+    }
+    ps.rayD()[slot] = mk4u(pd, gy * fp.width + gx + startingSeed);                                      // RNG seed (:564)
     ps.hit(RAY_MAIN)[slot] = sphere_seed(sc, rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]), pd);
     ps.att()[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));                                   // j = 0
     ps.total()[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));                                 // sample 0
@@ -1256,19 +1274,24 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
 // ---------------------------------------------------------------- k_resolve
 // raytrace.comp:574-593. `rgba` holds the previous frame when progressive
 // (kept in fp32 instead of the reference's 8-bit image).
-__device__ __forceinline__ void resolve_pixel(const PathState& ps, const FrameParams& fp, float4* rgba, uint32_t slot) {
-    rt_vec3 out = f4xyz(ps.accum()[slot]);
+// raytrace.comp:574-582 for one frame: sample mean, progressive blend with what the image holds, NaN/Inf -> magenta
+__device__ __forceinline__ rt_vec3 blend_frame(const FrameParams& fp, uint32_t frameCount, float4 oldc, float4 accum) {
+    rt_vec3 out = f4xyz(accum);
     float fs = (float)fp.samples;
     out = rt_v3(out.x / fs, out.y / fs, out.z / fs);
-    float weight = 1.f / ((float)fp.frameCount + 1.f);
-    uint32_t gx, gy, krow;
-    slot_to_pixel(fp, slot, gx, gy, krow);
-    const size_t px = (size_t)krow * fp.width + gx;
-    float4 oldc = rgba[px];
+    float weight = 1.f / ((float)frameCount + 1.f);
     rt_vec3 blended = rt_add(rt_scale(rt_v3(oldc.x, oldc.y, oldc.z), 1.f - weight), rt_scale(out, weight));
     rt_vec3 fin = fp.progressive ? blended : out;
     if (rt_isnan(fin.x) || rt_isnan(fin.y) || rt_isnan(fin.z) || rt_isinf(fin.x) || rt_isinf(fin.y) || rt_isinf(fin.z))
         fin = rt_v3(1.f, 0.f, 1.f);
+    return fin;
+}
+
+__device__ __forceinline__ void resolve_pixel(const PathState& ps, const FrameParams& fp, float4* rgba, uint32_t slot) {
+    uint32_t gx, gy, krow;
+    slot_to_pixel(fp, slot, gx, gy, krow);
+    const size_t px = (size_t)krow * fp.width + gx;
+    rt_vec3 fin = blend_frame(fp, fp.frameCount, rgba[px], ps.accum()[slot]);
     float s0 = (float)ps.statBox()[slot], s1 = (float)ps.statTri()[slot];
     float boxCap = (float)fp.boxCap, triCap = (float)fp.triCap;
     if (fp.debug == 0) {
@@ -1279,6 +1302,22 @@ __device__ __forceinline__ void resolve_pixel(const PathState& ps, const FramePa
         fin = rt_v3(s0 / boxCap, 0.f, s1 / triCap);
     }
     rgba[px] = make_float4(fin.x, fin.y, fin.z, 1.f);
+}
+
+// rt_render_frames: the frames of one launch blended into the image one after the other, in frame order, exactly as
+// nFrames dispatches would have done it (the sample sums of frame f's pixels wait in ps.accum()[frame_slot(f, slot)])
+__global__ __launch_bounds__(RT_BLOCK) void k_blend_frames(PathState ps, FrameParams fp, float4* rgba) {
+    const uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (slot >= fp.nPixels) return;  // `slot` is a slot of the tile here
+    uint32_t gx, gy, krow;
+    slot_to_pixel(fp, frame_slot(fp, 0u, slot), gx, gy, krow);
+    const size_t px = (size_t)krow * fp.width + gx;
+    float4 c = rgba[px];
+    for (uint32_t f = 0; f < fp.nFrames; f++) {
+        const rt_vec3 fin = blend_frame(fp, fp.frameCount + f, c, ps.accum()[frame_slot(fp, f, slot)]);
+        c = make_float4(fin.x, fin.y, fin.z, 1.f);
+    }
+    rgba[px] = c;
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void k_resolve(PathState ps, FrameParams fp, float4* rgba) {
@@ -1351,12 +1390,13 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
     const unsigned long long tKernelStart = fa.waveTimes ? wall_clock64() : 0ull;
     // scatter = g > 0: batchPixels is a multiple of g and a block is batchPixels / g chunks of g slots, nBatches apart
     const uint32_t nBatches = fa.scatter ? ((fp.nPixels + fa.scatter - 1) / fa.scatter + fa.batchPixels / fa.scatter - 1) / (fa.batchPixels / fa.scatter)
-                                         : (fp.nPixels + fa.batchPixels - 1) / fa.batchPixels;
+                                         : ((fp.nFrames > 1u ? ((fp.nPixels + 63u) >> 6) * 64u * fp.nFrames : fp.nPixels) + fa.batchPixels - 1) / fa.batchPixels;
 
     // A lane keeps a pixel until all its samples are done, then resolves it and takes the next one: when `pixelRefill`
     // of the wave's lanes are free (or all of them), the wave reserves that many slots with one atomic. The wave stays
     // populated until the tile runs out, instead of draining to its slowest pixel once per block.
-    const uint32_t total = fa.scatter ? nBatches * fa.batchPixels : fp.nPixels;
+    const uint32_t nSlots = fp.nFrames > 1u ? ((fp.nPixels + 63u) >> 6) * 64u * fp.nFrames : fp.nPixels;  // nFrames > 1 comes with scatter = 0
+    const uint32_t total = fa.scatter ? nBatches * fa.batchPixels : nSlots;
     const uint32_t refillAt = min(max(fa.pixelRefill, 1u), fa.batchPixels);
     uint32_t slot = 0;
     bool valid = false, alive = false, exhausted = false;
@@ -1377,7 +1417,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
                 const FusedKernArgs* kq = opaque_kernarg<FusedKernArgs>();
                 const FrameParams* fq = &kq->fp;
                 const DevScene* sq = &kq->sc;
-                if (valid) resolve_pixel(ps, *fq, fa.rgba, slot);
+                if (valid && fq->nFrames == 1u) resolve_pixel(ps, *fq, fa.rgba, slot);  // several frames: k_blend_frames, afterwards
                 const uint32_t a = base + lanes_below(mF);
                 uint32_t ns = a;
                 if (fa.scatter) {
@@ -1386,7 +1426,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
                     const uint32_t ch = a / fa.scatter, perBlock = fa.batchPixels / fa.scatter;
                     ns = ((ch % perBlock) * nBatches + ch / perBlock) * fa.scatter + a % fa.scatter;
                 }
-                valid = a < total && ns < fp.nPixels;
+                valid = a < total && ns < nSlots && (fq->nFrames == 1u || slot_in_tile(*fq, ns) < fq->nPixels);
                 slot = ns;
                 auxMask = 0;
                 if (valid) {
@@ -1443,7 +1483,7 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
     }
     if (valid) {  // the pixels that finished after the tile ran out
         const FusedKernArgs* kq = opaque_kernarg<FusedKernArgs>();
-        resolve_pixel(ps, kq->fp, fa.rgba, slot);
+        if (kq->fp.nFrames == 1u) resolve_pixel(ps, kq->fp, fa.rgba, slot);
     }
 
     if (fa.waveTimes && lane_id() == 0) {  // phase_stats: when did this wave run out of blocks?

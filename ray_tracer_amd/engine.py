@@ -259,6 +259,20 @@ class Renderer:
             return None
         return self.read_rgba()
 
+    def render_frames(self, pc, width, height, nFrames, row0=0, rowStride=1, nRows=None, out_ptr=None, sync=True):
+        """nFrames progressive dispatches starting at pc.frameCount (rt_render_frames): the frames share launches where one
+        frame would leave the GPU short of pixels. Same pixels as nFrames render() calls."""
+        if nRows is None:
+            nRows = (height - row0 + rowStride - 1) // rowStride
+        self.fill_counts(pc)
+        self._check(self._l.rt_render_frames(self._h, C.byref(pc), width, height, row0, rowStride, nRows, int(nFrames),
+                                             C.c_void_p(out_ptr) if out_ptr else None), "rt_render_frames")
+        self._shape = (nRows, width, 4)
+        if not sync:
+            return None
+        self.sync()
+        return None if out_ptr else self.read_rgba()
+
     def run_compute(self, pc, width, height, **tile):
         """Frame semantics of draw()/run_compute (src/vk_engine.cpp:1782,1812-1814); `tile` = row0 / rowStride / nRows
         of rt_render when the frame is split over several GPUs."""
@@ -277,6 +291,10 @@ class Renderer:
 
     def sync(self):
         self._check(self._l.rt_sync(self._h), "rt_sync")
+
+    def clear_framebuffer(self):
+        """A new progressive history: the next render into the context's own image starts from zeros."""
+        self._check(self._l.rt_clear_framebuffer(self._h), "rt_clear_framebuffer")
 
     def read_rgba(self):
         out = np.empty(self._shape, dtype=np.float32)

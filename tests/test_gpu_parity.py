@@ -737,3 +737,39 @@ def test_light_queries_on_and_off(renderer):
     finally:
         renderer.set_tuning("light_queries", 1)
         pyoracle.lib().oracle_set_light_queries(1)
+
+
+def test_render_frames_equals_frame_by_frame(renderer):
+    """rt_render_frames: several progressive frames of a tile in one launch (their pixels are independent until they are
+    blended) against the same frames dispatched one by one, and against the oracle's chain of dispatches — pixels and
+    counters, for a whole frame, an interleaved tile, a frame count that does not divide by the frames per launch, and the
+    non-progressive case (every frame overwrites the last)."""
+    s = model_scene("bunny.obj", material=0, spheres=True)
+    W, H = 96, 64
+    renderer.upload_scene(s)
+    try:
+        for tile, nF, f0, prog, fpl in ((dict(), 5, 0, 1, 0), (dict(row0=1, rowStride=3, nRows=len(range(1, H, 3))), 7, 2, 1, 3),
+                                        (dict(), 3, 4, 0, 0), (dict(), 1, 0, 1, 0)):
+            renderer.set_tuning("frames_per_launch", fpl)
+            rows = tile.get("nRows", H)
+            # frame by frame on the GPU (the context's own image keeps the progressive history), and the oracle's chain
+            ref = None
+            renderer.clear_framebuffer()
+            renderer.reset_counters()
+            for f in range(nF):
+                pc = engine.push_constants(W, H, raysPerPixel=2, progressive=prog, frameCount=f0 + f)
+                a = renderer.render(pc, W, H, **tile)
+                ref, _ = pyoracle.render(s, pc, W, H, prev=ref, **tile)
+            c_seq = renderer.counters()
+            # all at once
+            renderer.clear_framebuffer()
+            renderer.reset_counters()
+            pc = engine.push_constants(W, H, raysPerPixel=2, progressive=prog, frameCount=f0)
+            b = renderer.render_frames(pc, W, H, nF, **tile)
+            c_all = renderer.counters()
+            assert np.array_equal(a.view(np.uint32), ref.view(np.uint32)), "frame by frame differs from the oracle"
+            assert np.array_equal(b.view(np.uint32), a.view(np.uint32)), f"rt_render_frames differs (nFrames {nF}, tile {tile})"
+            for k in ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments", "emitterTests"):
+                assert c_all[k] == c_seq[k], k
+    finally:
+        renderer.set_tuning("frames_per_launch", 0)

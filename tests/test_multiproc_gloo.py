@@ -59,6 +59,18 @@ def test_two_ranks_stitch_to_the_single_process_frame(tmp_path):
     assert np.array_equal(got.view(np.uint32), full.view(np.uint32))
 
 
+def test_eight_ranks_stitch_an_uneven_frame(tmp_path):
+    """The 8-GPU partition (rows r, r+8, ...) on eight gloo ranks, 27 rows: three ranks get four rows, five get three."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import pyoracle
+    from ray_tracer_amd import engine
+    from util import cornell_scene
+    W, H = 32, 27
+    full, _ = pyoracle.render(cornell_scene(True), engine.push_constants(W, H, singleRender=1, sampleLimit=2), W, H)
+    got = _run(8, W, H, tmp_path)
+    assert np.array_equal(got.view(np.uint32), full.view(np.uint32))
+
+
 def test_row_assignment_covers_every_row_once():
     from ray_tracer_amd import tiling
     for H in (1, 7, 1080, 2160):

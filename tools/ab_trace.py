@@ -22,13 +22,17 @@ ap.add_argument("--phase-stats", action="store_true")
 ap.add_argument("--bounce", type=int, default=8)
 ap.add_argument("--ntris", type=int, default=0, help="sponza stand-in triangle count (0 = default)")
 ap.add_argument("--row-stride", type=int, default=1, help="render only rows 0, s, 2s, ... (what rank 0 of s GPUs renders)")
+ap.add_argument("--row0", type=int, default=0)
+ap.add_argument("--rows", type=int, default=0, help="rows of the tile (0 = all that fit)")
+ap.add_argument("--frames", type=int, default=1, help="progressive frames per measurement, submitted at once (rt_render_frames)")
 ap.add_argument("--variants", default="v0;v1,refill=8;v1,refill=16;v1,refill=24;v1,refill=32;v1,refill=48")
 args = ap.parse_args()
 
 scene, label = scenes.sponza(0, ntris=args.ntris) if (args.ntris and args.scene == 'sponza') else scenes.CONFIGS[args.scene]()
 cam = scenes.sponza_camera if args.scene.startswith("sponza") else engine.push_constants
 W, H = args.width, args.height
-pc = cam(W, H, singleRender=1, sampleLimit=args.spp, bounceLimit=args.bounce)
+pc = cam(W, H, singleRender=1, sampleLimit=args.spp, bounceLimit=args.bounce) if args.frames == 1 else \
+    cam(W, H, raysPerPixel=args.spp, progressive=1, bounceLimit=args.bounce)
 r = engine.Renderer(0)
 r.upload_scene(scene)
 if args.phase_stats:
@@ -51,7 +55,10 @@ for rnd in range(args.rounds + 1):
         r.reset_counters()
         r.set_profiling(True)
         t = time.perf_counter()
-        img = r.render(pc, W, H, row0=0, rowStride=args.row_stride)
+        if args.frames == 1:
+            img = r.render(pc, W, H, row0=args.row0, rowStride=args.row_stride, nRows=args.rows or None)
+        else:
+            img = r.render_frames(pc, W, H, args.frames, row0=args.row0, rowStride=args.row_stride, nRows=args.rows or None)
         dt = (time.perf_counter() - t) * 1e3
         tms, nl = r.trace_time_ms()
         r.set_profiling(False)

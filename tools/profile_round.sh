@@ -1,19 +1,25 @@
 #!/bin/bash
-# The judged evidence of a round, in one go: bench line, rocprofv3 kernel stats of the same command, and the two PMC
-# passes for HBM-side traffic (FETCH_SIZE, WRITE_SIZE; separate runs). usage: tools/profile_round.sh <tag>   (on the GPU box)
+# The judged evidence of a round, in one go (on the GPU box): bench line, rocprofv3 kernel stats of the same command, and
+# the PMC passes (HBM-side traffic, TA / VALU / L1 counters) reduced to one JSON that bench.py quotes in `roofline`.
+# usage: tools/profile_round.sh <tag> [extra bench.py arguments]      results under gpurun_out/<tag>/
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-tag=$1
+tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p $out
-CMD="python3 bench.py --steps 3 --warmup 1 --spp 8"
+CMD="python3 bench.py --steps 3 --warmup 1 --spp 8 $*"
 timeout -k 10 400 $CMD > $out/bench.log 2>&1 || { tail -5 $out/bench.log; exit 1; }
-tail -1 $out/bench.log > $out/bench.json
+grep '^{' $out/bench.log | tail -1 > $out/bench.json
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD --cpu-seconds 0 > $out/bench_under_rocprof.log 2>&1 || { tail -5 $out/bench_under_rocprof.log; exit 1; }
 grep '^{' $out/bench_under_rocprof.log | tail -1 > $out/bench_under_rocprof.json
 cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- $CMD --cpu-seconds 0 --no-profile > $out/fetch.log 2>&1 || { tail -5 $out/fetch.log; exit 1; }
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- $CMD --cpu-seconds 0 --no-profile > $out/write.log 2>&1 || { tail -5 $out/write.log; exit 1; }
 kern=$(python3 -c "import json; print('k_render_fused' if 'fused' in json.load(open('$out/bench.json'))['config']['pipeline'] else 'k_trace_pw')")
-python tools/pmc_traffic.py $(find $out/fetch -name '*counter_collection.csv' | head -1) $(find $out/write -name '*counter_collection.csv' | head -1) $kern $out/traffic_$kern.json "python3 bench.py --steps 3 --warmup 1 --spp 8 (Sponza 1920x1080)"
-rm -rf $out/stats $out/fetch $out/write
-cat $out/bench.json | cut -c1-300; head -5 $out/kernel_stats.csv; cat $out/traffic_$kern.json
+# one pass per counter group: TCC (FETCH_SIZE alone, WRITE_SIZE alone), SQ, TA/TCP; GRBM rides along
+i=0
+for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_FLAT_READ_WAVEFRONTS_sum"; do
+  i=$((i+1))
+  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc/pass_$i -- $CMD --cpu-seconds 0 --no-profile > $out/pmc_$i.log 2>&1 || { echo "pmc pass $i ($set) failed"; tail -5 $out/pmc_$i.log; }
+  [ $i = 1 ] && grep '^{' $out/pmc_$i.log | tail -1 > $out/pmc/bench_pass.json
+done
+python3 tools/pmc_roofline.py $out/pmc $kern $out/counters_$kern.json "$CMD (PMC passes: --cpu-seconds 0 --no-profile)" > $out/pmc_roofline.log 2>&1 || tail -5 $out/pmc_roofline.log
+rm -rf $out/stats $out/pmc
+cut -c1-400 $out/bench.json; head -4 $out/kernel_stats.csv; cat $out/counters_$kern.json
