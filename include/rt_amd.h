@@ -350,6 +350,24 @@ int  rt_bvh_hook(void* ctx, const TrianglePoint* points, uint32_t pointCount, Tr
 /* milliseconds the last rt_bvh_build spent between its first upload and its last download */
 double rt_bvh_last_build_ms(const rt_ctx* ctx);
 
+/* ------------------------------------------------------------------ */
+/* Several GPUs of one node: one process (and one ctx) per GPU            */
+/* ------------------------------------------------------------------ */
+/* The frame shards by image rows with no exchange while it renders (a pixel depends on its global index and the read-only
+ * scene, raytrace.comp:563-564): rank r of N calls rt_render / rt_render_frames with row0 = r, rowStride = N into a strip of
+ * its own, and one gather at the end brings the strips to one rank. These four calls are that gather, over RCCL (xGMI):
+ *   rank 0:      rt_comm_unique_id(id), hands the RT_COMM_ID_BYTES to the other processes by any means it has
+ *   every rank:  rt_comm_init(ctx, id, N, r)
+ *   every rank:  rt_gather_strips(ctx, d_strip, W, H, root, d_frame)  — asynchronous on the ctx stream, rt_sync waits
+ * RCCL is loaded on the first of these calls; a single-GPU host never needs it. */
+enum { RT_COMM_ID_BYTES = 128 };   /* sizeof(ncclUniqueId) */
+int  rt_comm_unique_id(void* idOut);
+int  rt_comm_init(rt_ctx* ctx, const void* id, int nRanks, int rank);
+int  rt_comm_destroy(rt_ctx* ctx);
+/* d_strip: this rank's rows rank, rank + N, ... of a width x height RGBA fp32 frame, in that order (what rt_render wrote);
+ * d_frame: the whole frame, on `root` only (NULL elsewhere). Every rank of the communicator must call it. */
+int  rt_gather_strips(rt_ctx* ctx, const float* d_strip, uint32_t width, uint32_t height, int root, float* d_frame);
+
 /* device self-test of the deterministic-math build (must equal RT_SELFTEST_EXPECT) */
 int  rt_device_selftest(rt_ctx* ctx, uint32_t* bitsOut);
 uint32_t rt_host_selftest(void);

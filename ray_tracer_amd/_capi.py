@@ -143,6 +143,10 @@ SYMBOLS = {
     "rt_bvh_build": (C.c_int, [_vp, _P(TrianglePoint), C.c_uint32, _P(Triangle), _P(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, _P(BVHNode), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
     "rt_bvh_hook": (C.c_int, [_vp, _P(TrianglePoint), C.c_uint32, _P(Triangle), _P(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, _P(BVHNode), C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
     "rt_bvh_last_build_ms": (C.c_double, [_vp]),
+    "rt_comm_unique_id": (C.c_int, [_vp]),
+    "rt_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "rt_comm_destroy": (C.c_int, [_vp]),
+    "rt_gather_strips": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_int, _vp]),
     "rt_device_selftest": (C.c_int, [_vp, _P(C.c_uint32)]),
     "rt_host_selftest": (C.c_uint32, []),
     "rt_device_math_probe": (C.c_int, [_vp, C.c_uint32, _P(C.c_float), _P(C.c_float)]),

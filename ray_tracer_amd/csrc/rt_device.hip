@@ -9,6 +9,9 @@
 #include "rt_kernels.hip.h"
 #include "bvh_build.hip.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -43,6 +46,10 @@ struct rt_ctx {
     // host copies of what the emitter list is derived from (rebuild_emitters)
     std::vector<RayMaterial> hostMats;
     std::vector<uint32_t> hostSphereMat, hostObjMat, hostObjRoot;
+    // multi-GPU (rt_comm_*): this rank's RCCL communicator, a staging buffer on the gathering rank
+    ncclComm_t comm = nullptr;
+    int commRanks = 0, commRank = 0;
+    DevBuf gatherBuf;
     int framesPerLaunch = 0; // rt_render_frames: most frames of a tile rendered by one launch (0 = as many as fit)
     int lightQueries = 1;   // rt_set_tuning("light_queries", 0): trace every NEE ray and cosine probe in full
     uint32_t maxLeafDepth = 0;
@@ -475,6 +482,8 @@ void rt_destroy(rt_ctx* c) {
     for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->emitBuf, &c->stateBuf,
                       &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf, &c->waveTimeBuf, &c->probeBuf})
         dev_free(*b);
+    (void)rt_comm_destroy(c);
+    dev_free(c->gatherBuf);
     for (auto& e : c->evPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->hostCounts) (void)hipHostFree(c->hostCounts);
     if (c->snap) (void)hipHostFree(c->snap);
@@ -1361,6 +1370,125 @@ int rt_device_selftest(rt_ctx* c, uint32_t* bitsOut) {
     // bit 31 set: device and host disagree on some primitive
     *bitsOut = bits | (mismatches ? 0x80000000u : 0u);
     if (mismatches) return c->fail("device/host deterministic-math mismatch in " + std::to_string(mismatches) + " of 4096 probes");
+    return 0;
+}
+
+// ---------------------------------------------------------------- multi-GPU: the final gather over RCCL
+// One process per GPU, one rt_ctx per process. RCCL is loaded when the first rt_comm_* call needs it (a host that
+// renders on one GPU never touches it); the typed function pointers keep the calls checked against <rccl/rccl.h>.
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+    decltype(&ncclCommInitRank) commInitRank = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclGroupStart) groupStart = nullptr;
+    decltype(&ncclGroupEnd) groupEnd = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGetErrorString) errorString = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("RCCL not found: ") + dlerror(); return false; }
+        getUniqueId = (decltype(getUniqueId))dlsym(lib, "ncclGetUniqueId");
+        commInitRank = (decltype(commInitRank))dlsym(lib, "ncclCommInitRank");
+        commDestroy = (decltype(commDestroy))dlsym(lib, "ncclCommDestroy");
+        groupStart = (decltype(groupStart))dlsym(lib, "ncclGroupStart");
+        groupEnd = (decltype(groupEnd))dlsym(lib, "ncclGroupEnd");
+        send = (decltype(send))dlsym(lib, "ncclSend");
+        recv = (decltype(recv))dlsym(lib, "ncclRecv");
+        errorString = (decltype(errorString))dlsym(lib, "ncclGetErrorString");
+        if (!getUniqueId || !commInitRank || !commDestroy || !groupStart || !groupEnd || !send || !recv || !errorString) {
+            err = "RCCL library lacks a required symbol";
+            dlclose(lib); lib = nullptr;
+            return false;
+        }
+        return true;
+    }
+} g_rccl;
+
+int rccl_fail(rt_ctx* c, ncclResult_t r, const char* what) {
+    c->error = std::string(what) + ": " + (g_rccl.errorString ? g_rccl.errorString(r) : "?");
+    return -2000 - (int)r;
+}
+}  // namespace
+
+static_assert(RT_COMM_ID_BYTES == sizeof(ncclUniqueId), "rt_amd.h: RT_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+
+int rt_comm_unique_id(void* idOut) {
+    if (!idOut) return -1;
+    if (!g_rccl.load()) return -2;
+    ncclUniqueId id;
+    if (g_rccl.getUniqueId(&id) != ncclSuccess) return -3;
+    memcpy(idOut, &id, sizeof(id));
+    return 0;
+}
+
+int rt_comm_init(rt_ctx* c, const void* id, int nRanks, int rank) {
+    if (!c || !id) return -1;
+    if (nRanks < 1 || rank < 0 || rank >= nRanks) return c->fail("rt_comm_init: rank out of range");
+    if (c->comm) return c->fail("rt_comm_init: this context already has a communicator");
+    if (!g_rccl.load()) return c->fail(g_rccl.err);
+    RT_HIP(c, hipSetDevice(c->device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    ncclResult_t r = g_rccl.commInitRank(&c->comm, nRanks, uid, rank);
+    if (r != ncclSuccess) { c->comm = nullptr; return rccl_fail(c, r, "ncclCommInitRank"); }
+    c->commRanks = nRanks; c->commRank = rank;
+    return 0;
+}
+
+int rt_comm_destroy(rt_ctx* c) {
+    if (!c) return -1;
+    if (c->comm) {
+        (void)hipStreamSynchronize(c->stream);
+        g_rccl.commDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->commRanks = 0;
+    return 0;
+}
+
+int rt_gather_strips(rt_ctx* c, const float* d_strip, uint32_t width, uint32_t height, int root, float* d_frame) {
+    if (!c || !d_strip) return -1;
+    if (!c->comm) return c->fail("rt_gather_strips before rt_comm_init");
+    const int N = c->commRanks, me = c->commRank;
+    if (root < 0 || root >= N) return c->fail("rt_gather_strips: root out of range");
+    if (me == root && !d_frame) return c->fail("rt_gather_strips: the root needs d_frame");
+    RT_HIP(c, hipSetDevice(c->device));
+    auto rows_of = [&](int r) { return (uint32_t)r < height ? (height - (uint32_t)r + (uint32_t)N - 1u) / (uint32_t)N : 0u; };
+    const size_t rowFloats = (size_t)width * 4;
+    float* stage = nullptr;
+    if (me == root) {
+        int rc = dev_alloc(c, c->gatherBuf, (size_t)height * rowFloats * sizeof(float));
+        if (rc) return rc;
+        stage = (float*)c->gatherBuf.p;
+    }
+    // every rank's strip goes to the root over its own link: one send per rank, N receives on the root, one group
+    ncclResult_t r = g_rccl.groupStart();
+    if (r != ncclSuccess) return rccl_fail(c, r, "ncclGroupStart");
+    if (rows_of(me)) r = g_rccl.send(d_strip, (size_t)rows_of(me) * rowFloats, ncclFloat, root, c->comm, c->stream);
+    if (r == ncclSuccess && me == root) {
+        size_t at = 0;
+        for (int k = 0; k < N && r == ncclSuccess; k++) {
+            if (rows_of(k)) r = g_rccl.recv(stage + at, (size_t)rows_of(k) * rowFloats, ncclFloat, k, c->comm, c->stream);
+            at += (size_t)rows_of(k) * rowFloats;
+        }
+    }
+    ncclResult_t e = g_rccl.groupEnd();
+    if (r != ncclSuccess) return rccl_fail(c, r, "ncclSend/ncclRecv");
+    if (e != ncclSuccess) return rccl_fail(c, e, "ncclGroupEnd");
+    if (me == root) {  // strips (rank-major) -> image rows: row y came from rank y % N, its row y / N
+        const size_t n4 = (size_t)height * width;
+        hipLaunchKernelGGL(k_deinterleave_rows, dim3((unsigned)((n4 + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, c->stream,
+                           (const float4*)stage, (float4*)d_frame, width, height, (uint32_t)N);
+        RT_HIP(c, hipGetLastError());
+    }
     return 0;
 }
 

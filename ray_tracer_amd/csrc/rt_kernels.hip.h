@@ -1579,6 +1579,19 @@ __global__ void k_selftest(const float* a, const float* b, uint32_t n, uint32_t*
     if (i == 0) *bitsOut = rt_selftest_bits(kat);
 }
 
+// rt_gather_strips on the gathering rank: strips stored rank after rank (rank r: image rows r, r + n, ...) -> image rows
+__global__ __launch_bounds__(RT_BLOCK) void k_deinterleave_rows(const float4* __restrict__ strips, float4* __restrict__ frame, uint32_t width,
+                                                                uint32_t height, uint32_t nRanks) {
+    const size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= (size_t)width * height) return;
+    const uint32_t y = (uint32_t)(i / width), x = (uint32_t)(i - (size_t)y * width);
+    const uint32_t r = y % nRanks, k = y / nRanks;
+    // rows of the ranks before r: rank q has ceil((height - q) / nRanks) rows
+    const uint32_t full = height / nRanks, extra = height % nRanks;
+    const size_t before = (size_t)r * full + (r < extra ? r : extra);
+    frame[i] = strips[(before + k) * width + x];
+}
+
 // include/rt_probe.h on the device: the raw values of every GLSL built-in, for tests/test_glsl_builtins.py
 __global__ void k_math_probe(const float* in, float* out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

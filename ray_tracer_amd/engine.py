@@ -352,6 +352,26 @@ class Renderer:
         self._check(self._l.rt_device_selftest(self._h, C.byref(b)), "rt_device_selftest")
         return b.value
 
+    # -- several GPUs, one process each: the final gather over RCCL through the C ABI (rt_comm_*) --------------
+    @staticmethod
+    def comm_unique_id():
+        """On rank 0: the RT_COMM_ID_BYTES every rank passes to comm_init (hand them over by any means)."""
+        buf = C.create_string_buffer(128)
+        if _capi.lib().rt_comm_unique_id(buf) != 0:
+            raise RtError("rt_comm_unique_id failed: RCCL could not be loaded")
+        return buf.raw
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        self._check(self._l.rt_comm_init(self._h, C.c_char_p(unique_id), int(n_ranks), int(rank)), "rt_comm_init")
+
+    def comm_destroy(self):
+        self._check(self._l.rt_comm_destroy(self._h), "rt_comm_destroy")
+
+    def gather_strips(self, strip_ptr, width, height, root=0, frame_ptr=None):
+        """This rank's strip (device pointer) -> the whole frame on `root` (device pointer there, None elsewhere)."""
+        self._check(self._l.rt_gather_strips(self._h, C.c_void_p(strip_ptr), width, height, int(root),
+                                             C.c_void_p(frame_ptr) if frame_ptr else None), "rt_gather_strips")
+
     def math_probe(self, inputs):
         """include/rt_probe.h evaluated on the device: [n, 32] float32 -> [n, 64] float32."""
         x = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 32)
