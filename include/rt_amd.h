@@ -194,6 +194,14 @@ int  rt_scene_cornell_box(rt_scene* s, const char* assetDir);
  * zeroed spheres, the six built-in materials, the two cubes, cornell_box. */
 int  rt_scene_prepare_default(rt_scene* s, const char* assetDir);
 int  rt_scene_get_arrays(const rt_scene* s, RtSceneArrays* out);
+/* The texture slots the MTL files claimed, in slot order (textures[texturesUsed], src/vk_engine.cpp:1109-1141): the host
+ * decodes file i to RGBA8 (the reference: stb_image, STBI_rgb_alpha, src/vk_textures.cpp:103-113) and hands all of them to
+ * rt_upload_textures. rt_scene_add_texture claims the next slot for a file no MTL names (bind it with a material's
+ * albedoIndex); rt_scene_set_material overwrites rayMaterials[i] (the material editor's in-place edit, :1536-1545). */
+uint32_t rt_scene_texture_count(const rt_scene* s);
+const char* rt_scene_texture_path(const rt_scene* s, uint32_t i);
+int  rt_scene_add_texture(rt_scene* s, const char* path);
+int  rt_scene_set_material(rt_scene* s, uint32_t i, const RayMaterial* m);
 /* index of a material loaded from an MTL file, key "<mtlpath>/<name>"; -1 if absent */
 int  rt_scene_find_material(const rt_scene* s, const char* key);
 /* BVH build statistics of the most recent build (printed by the reference, :1187-1193) */
@@ -265,6 +273,17 @@ int  rt_set_stream(rt_ctx* ctx, void* hipStream);
 /* copy_buffer x6 (src/vk_engine.cpp:686,753-757): takes the reference's AoS
  * host arrays, converts to the device layouts, uploads. Borrowed for the call. */
 int  rt_upload_scene(rt_ctx* ctx, const RtSceneArrays* scene);
+/* Textures (bindings raytrace.comp:122,148, upload src/vk_textures.cpp:103-200). Slot i of the scene's texture
+ * table, as R8G8B8A8_SRGB texels, rows top to bottom (what stbi_load(..., STBI_rgb_alpha) returns). The snapshot's shader
+ * computes hit.uv (raytrace.comp:249-256) and never samples; the semantics here are this build's declared choice
+ * ("parity unpinned"): a triangle hit whose material has albedoIndex >= 0 multiplies the material's albedo by
+ * the texel at hit.uv — nearest filter, sampler RenderObject.samplerIndex (0 = repeat, 1 = clamp to edge, :525-531),
+ * sRGB -> linear. Borrowed for the call; n = 0 removes all textures. */
+typedef struct RtTexture {
+    uint32_t width, height;
+    const uint8_t* rgba8;   /* width * height * 4 bytes */
+} RtTexture;
+int  rt_upload_textures(rt_ctx* ctx, const RtTexture* textures, uint32_t n);
 /* update_buffer (src/vk_engine.cpp:1545,1572,1603) */
 int  rt_update_materials(rt_ctx* ctx, const RayMaterial* m, uint32_t n);
 int  rt_update_spheres(rt_ctx* ctx, const Sphere* s, uint32_t n);

@@ -281,6 +281,29 @@ RT_HD void rt_mat4_inverse(const float* m, float* o) {
 }
 
 
+/* ---------------------------------------------------------------- textures
+ * The snapshot's shader declares TextureBuffer[64] / TextureSampler[2] (raytrace.comp:122,148) and interpolates hit.uv
+ * (:249-256) but never samples; the semantics below are this build's declared choice, from what the host sets up:
+ * VK_FORMAT_R8G8B8A8_SRGB images (src/vk_engine.cpp:1158), VK_FILTER_NEAREST with sampler 0 = REPEAT and sampler 1 =
+ * CLAMP_TO_EDGE (:525-531), selected by RenderObject.samplerIndex. */
+/* texel index along one axis for VK_FILTER_NEAREST: floor(coord * size), wrapped (REPEAT) or clamped (CLAMP_TO_EDGE);
+ * NaN and |coord * size| >= 2^30 give 0 */
+RT_HD uint32_t rt_tex_index(float coord, uint32_t size, bool clampToEdge) {
+    float f = coord * (float)size;
+    if (!(rt_abs(f) < 1073741824.f)) return 0u;
+    int i = (int)f;
+    if ((float)i > f) i -= 1; /* floor */
+    int n = (int)size;
+    if (clampToEdge) return (uint32_t)(i < 0 ? 0 : (i > n - 1 ? n - 1 : i));
+    int r = i % n;
+    return (uint32_t)(r < 0 ? r + n : r);
+}
+/* one channel of an R8G8B8A8_SRGB texel -> linear (the sRGB transfer function, evaluated with rt_pow) */
+RT_HD float rt_srgb8_to_linear(uint32_t byte) {
+    float c = (float)byte / 255.f;
+    return c <= 0.04045f ? c / 12.92f : rt_pow((c + 0.055f) / 1.055f, 2.4f);
+}
+
 /* ---------------------------------------------------------------- RNG (raytrace.comp:158-163) */
 RT_HD float rt_random(uint32_t* state) {
     uint32_t s = *state * 747796405u + 2891336453u;

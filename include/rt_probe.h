@@ -7,12 +7,13 @@
  * rt_device_math_probe — with restatements of the GLSL 4.50 formulas written independently in numpy float32.
  * It contains no arithmetic of its own.
  *
- * in[32]:  0-2 I   3-5 N   6 eta   7 x   8 e0   9 e1   10 a   11 y   12-14 V   15 unused   16-31 M (column-major mat4)
+ * in[32]:  0-2 I   3-5 N   6 eta   7 x   8 e0   9 e1   10 a   11 y   12-14 V   15 byte (0..255, as float)   16-31 M (column-major mat4)
  * out[64]: 0-2 reflect(I,N)   3-5 refract(I,N,eta)   6 smoothstep(e0,e1,x)   7 mix(x,y,a)   8 sign(x)   9-11 normalize(I)
  *          12 tan(x)   13 radians(x)   14-16 cross(I,V)   17 dot(I,V)   18 min(x,y)   19 max(x,y)   20 sin(x)   21 cos(x)
  *          22 log2(|x|)   23 exp2(x)   24 pow(|x|,y)   25 sqrt(|x|)   26 abs(x)   27 isnan(x)   28 isinf(x)
  *          29 random(bits of x): the float   30 ... the new state (as float bits)   31 1/x (IEEE division)
- *          32-34 (M*vec4(V,0)).xyz   35-37 (M*vec4(V,1)).xyz   38-53 inverse(M)   54-63 zero
+ *          32-34 (M*vec4(V,0)).xyz   35-37 (M*vec4(V,1)).xyz   38-53 inverse(M)
+ *          54 srgb8_to_linear(byte = in[15])   55 tex_index(x, 37, repeat)   56 tex_index(x, 37, clamp)   57-63 zero
  */
 #ifndef RT_PROBE_H
 #define RT_PROBE_H
@@ -56,7 +57,10 @@ RT_HD void rt_math_probe(const float* in, float* out) {
     r = rt_xform_point(in + 16, V);
     out[35] = r.x; out[36] = r.y; out[37] = r.z;
     rt_mat4_inverse(in + 16, out + 38);
-    for (int k = 54; k < 64; k++) out[k] = 0.f;
+    out[54] = rt_srgb8_to_linear((uint32_t)in[15]);
+    out[55] = (float)rt_tex_index(x, 37u, false);
+    out[56] = (float)rt_tex_index(x, 37u, true);
+    for (int k = 57; k < 64; k++) out[k] = 0.f;
 }
 
 #endif /* RT_PROBE_H */

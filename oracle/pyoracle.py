@@ -10,7 +10,7 @@ import subprocess
 
 import numpy as np
 
-from ray_tracer_amd._capi import PushConstants, RtHit, RtSceneArrays
+from ray_tracer_amd._capi import PushConstants, RtHit, RtSceneArrays, RtTexture
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
@@ -62,6 +62,8 @@ def lib():
                                         C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(RtHit)]
         l.oracle_set_light_queries.restype = None
         l.oracle_set_light_queries.argtypes = [C.c_int]
+        l.oracle_set_textures.restype = None
+        l.oracle_set_textures.argtypes = [C.POINTER(RtTexture), C.c_uint32]
         l.oracle_random.restype = C.c_float
         l.oracle_random.argtypes = [C.POINTER(C.c_uint32)]
         l.oracle_math_probe.restype = None
@@ -126,3 +128,16 @@ def glsl_probe(inputs):
     fp = C.POINTER(C.c_float)
     lib().oracle_glsl_probe(x.shape[0], x.ctypes.data_as(fp), out.ctypes.data_as(fp))
     return out
+
+
+def set_textures(images):
+    """The scene's texture table for the next render() calls: a list of uint8 arrays [h, w, 4] (R8G8B8A8_SRGB), [] = none."""
+    arr = (RtTexture * max(len(images), 1))()
+    keep = []
+    for i, im in enumerate(images):
+        im = np.ascontiguousarray(im, dtype=np.uint8)
+        assert im.ndim == 3 and im.shape[2] == 4
+        keep.append(im)
+        arr[i].width, arr[i].height = im.shape[1], im.shape[0]
+        arr[i].rgba8 = im.ctypes.data_as(C.POINTER(C.c_uint8))
+    lib().oracle_set_textures(arr, len(images))

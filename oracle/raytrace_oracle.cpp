@@ -45,6 +45,7 @@ struct HitInfo {
     rt_vec3 hitPoint{0, 0, 0};
     rt_vec3 normal{0, 0, 0};
     float dst = 0.f;
+    float uv[2] = {0.f, 0.f};    // raytrace.comp:80; only triangle hits set it (:249-256)
     uint32_t objectHitIndex = 0;
     uint32_t triHitIndex = 0;
     uint32_t materialIndex = 0;  // defined as 0 where the shader leaves it unset
@@ -110,7 +111,7 @@ HitInfo sphereIntersection(const Sphere& sphere, const Ray& ray) {
     return h;
 }
 
-// raytrace.comp:227-261 (uv interpolation omitted: hit.uv is never read)
+// raytrace.comp:227-261
 HitInfo triangleIntersection(const Ray& ray, const TrianglePoint& p0, const TrianglePoint& p1,
                              const TrianglePoint& p2, bool frontOnly) {
     rt_vec3 v0 = rt_v3(p0.position[0], p0.position[1], p0.position[2]);
@@ -138,6 +139,11 @@ HitInfo triangleIntersection(const Ray& ray, const TrianglePoint& p0, const Tria
     rt_vec3 n2 = rt_v3(p2.normal[0], p2.normal[1], p2.normal[2]);
     rt_vec3 ni = rt_add(rt_add(rt_scale(n0, w), rt_scale(n1, u)), rt_scale(n2, v));
     hit.normal = rt_scale(ni, hit.frontFace ? 1.f : -1.f);
+    // hit.uv = w * v0uv + u * v1uv + v * v2uv; (0.5, 0.5) when two corners share their uv (:249-256)
+    const float u0 = p0.position[3], v0u = p0.normal[3], u1 = p1.position[3], v1u = p1.normal[3], u2 = p2.position[3], v2u = p2.normal[3];
+    hit.uv[0] = (w * u0 + u * u1) + v * u2;
+    hit.uv[1] = (w * v0u + u * v1u) + v * v2u;
+    if ((u0 == u1 && v0u == v1u) || (u1 == u2 && v1u == v2u) || (u2 == u0 && v2u == v0u)) { hit.uv[0] = 0.5f; hit.uv[1] = 0.5f; }
     return hit;
 }
 
@@ -316,6 +322,21 @@ float emitter_min_t(const Scene& sc, const Ray& ray, uint64_t& tested) {
     return tE;
 }
 
+// Textures. The snapshot's shader never samples one; this is the declared semantics of include/rt_amd.h
+// (rt_upload_textures): albedo *= texel(material.albedoIndex, hit.uv), nearest filter, sampler by object.samplerIndex
+// (0 repeat, 1 clamp to edge, src/vk_engine.cpp:525-531), R8G8B8A8_SRGB decoded to linear. Parity unpinned.
+struct OracleTexture { uint32_t width, height; std::vector<uint8_t> rgba; };
+std::vector<OracleTexture> g_textures;
+
+rt_vec3 albedoTexel(const Scene& sc, const HitInfo& hit, const RayMaterial& m) {
+    if (m.albedoIndex < 0 || (size_t)m.albedoIndex >= g_textures.size() || hit.isSphere) return rt_v3(1.f, 1.f, 1.f);
+    const OracleTexture& t = g_textures[(size_t)m.albedoIndex];
+    const bool clampEdge = sc.a.objects[hit.objectHitIndex].samplerIndex == 1u;
+    const uint32_t x = rt_tex_index(hit.uv[0], t.width, clampEdge), y = rt_tex_index(hit.uv[1], t.height, clampEdge);
+    const uint8_t* px = &t.rgba[((size_t)y * t.width + x) * 4];
+    return rt_v3(rt_srgb8_to_linear(px[0]), rt_srgb8_to_linear(px[1]), rt_srgb8_to_linear(px[2]));
+}
+
 struct PathCtx {
     const Scene& sc;
     const PushConstants& pc;
@@ -361,6 +382,7 @@ void executed_light_query(PathCtx& c, const Ray& ray, const Tally& fullTally, co
 BxDFResult diffuseBRDF(PathCtx& c, const HitInfo& prevHit, uint32_t& state, Tally aux[3], HitInfo auxHit[3], Ray auxRay[2]) {
     const RayMaterial& hitMaterial = c.sc.a.materials[prevHit.materialIndex];
     rt_vec3 albedo = rt_v3(hitMaterial.albedo[0], hitMaterial.albedo[1], hitMaterial.albedo[2]);
+    if (!g_textures.empty() && hitMaterial.albedoIndex >= 0 && !prevHit.isSphere) albedo = rt_mul(albedo, albedoTexel(c.sc, prevHit, hitMaterial));
     rt_vec3 origin = rt_add(prevHit.hitPoint, rt_scale(prevHit.normal, 0.01f));
 
     rt_vec3 lightSample = lightSampleDir(origin, state);
@@ -594,6 +616,17 @@ bool g_lightQueries = true;
 }  // namespace
 
 extern "C" {
+
+// the texture table of the scene the next oracle_render calls use (rt_upload_textures); n = 0 removes it
+void oracle_set_textures(const RtTexture* tex, uint32_t n) {
+    g_textures.clear();
+    for (uint32_t i = 0; i < n; i++) {
+        OracleTexture t;
+        t.width = tex[i].width; t.height = tex[i].height;
+        t.rgba.assign(tex[i].rgba8, tex[i].rgba8 + (size_t)t.width * t.height * 4);
+        g_textures.push_back(std::move(t));
+    }
+}
 
 // mirrors rt_set_tuning("light_queries", v): which definition of "executed work" the counters follow (pixels never change)
 void oracle_set_light_queries(int on) { g_lightQueries = on != 0; }

@@ -81,6 +81,10 @@ class RtSceneArrays(C.Structure):
                 ("bvhNodes", C.POINTER(BVHNode)), ("bvhNodeCount", C.c_uint32)]
 
 
+class RtTexture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgba8", C.POINTER(C.c_uint8))]
+
+
 class RtCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference",
                                           "paths", "segments", "traceLaunches", "emitterTests")]
@@ -111,6 +115,10 @@ SYMBOLS = {
     "rt_scene_cornell_box": (C.c_int, [_vp, C.c_char_p]),
     "rt_scene_prepare_default": (C.c_int, [_vp, C.c_char_p]),
     "rt_scene_get_arrays": (C.c_int, [_vp, _P(RtSceneArrays)]),
+    "rt_scene_texture_count": (C.c_uint32, [_vp]),
+    "rt_scene_texture_path": (C.c_char_p, [_vp, C.c_uint32]),
+    "rt_scene_add_texture": (C.c_int, [_vp, C.c_char_p]),
+    "rt_scene_set_material": (C.c_int, [_vp, C.c_uint32, _P(RayMaterial)]),
     "rt_scene_find_material": (C.c_int, [_vp, C.c_char_p]),
     "rt_scene_last_bvh_stats": (C.c_int, [_vp, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
     "rt_scene_set_bvh_hook": (C.c_int, [_vp, _vp, _vp]),
@@ -123,6 +131,7 @@ SYMBOLS = {
     "rt_last_error": (C.c_char_p, [_vp]),
     "rt_set_stream": (C.c_int, [_vp, _vp]),
     "rt_upload_scene": (C.c_int, [_vp, _P(RtSceneArrays)]),
+    "rt_upload_textures": (C.c_int, [_vp, _P(RtTexture), C.c_uint32]),
     "rt_update_materials": (C.c_int, [_vp, _P(RayMaterial), C.c_uint32]),
     "rt_update_spheres": (C.c_int, [_vp, _P(Sphere), C.c_uint32]),
     "rt_update_objects": (C.c_int, [_vp, _P(RenderObject), C.c_uint32]),

@@ -42,6 +42,7 @@ struct rt_ctx {
     // scene
     DevScene sc{};
     std::vector<DevBuf> sceneBufs;
+    DevBuf texelBuf, texInfoBuf, triUVBuf;
     DevBuf matBuf, sphereBuf, sphereMatBuf, objInvBuf, objFwdBuf, objMetaBuf, objBoxBuf, objSkipBuf, maskBoxBuf, emitBuf;
     // host copies of what the emitter list is derived from (rebuild_emitters)
     std::vector<RayMaterial> hostMats;
@@ -156,7 +157,9 @@ void pack_materials(const RayMaterial* m, uint32_t n, std::vector<float4>& out) 
     for (uint32_t i = 0; i < n; i++) {
         out[3 * i + 0] = make_float4(m[i].albedo[0], m[i].albedo[1], m[i].albedo[2], m[i].reflectance);
         out[3 * i + 1] = make_float4(m[i].emissionColor[0], m[i].emissionColor[1], m[i].emissionColor[2], m[i].emissionStrength);
-        out[3 * i + 2] = make_float4(m[i].ior, 0.f, 0.f, 0.f);
+        float ai;
+        memcpy(&ai, &m[i].albedoIndex, 4);   // bits of the int; -1 = no texture
+        out[3 * i + 2] = make_float4(m[i].ior, ai, 0.f, 0.f);
     }
 }
 
@@ -479,7 +482,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->sceneBufs) dev_free(b);
-    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->emitBuf, &c->stateBuf,
+    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->emitBuf, &c->texelBuf, &c->texInfoBuf, &c->triUVBuf, &c->stateBuf,
                       &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf, &c->waveTimeBuf, &c->probeBuf})
         dev_free(*b);
     (void)rt_comm_destroy(c);
@@ -499,6 +502,29 @@ int rt_set_stream(rt_ctx* c, void* s) {
     if (!c) return -1;
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->stream = s ? (hipStream_t)s : c->ownStream;
+    return 0;
+}
+
+int rt_upload_textures(rt_ctx* c, const RtTexture* tex, uint32_t n) {
+    if (!c || (!tex && n)) return -1;
+    if (n > (uint32_t)RT_MAX_TEXTURES) return c->fail("more than RT_MAX_TEXTURES textures");
+    RT_HIP(c, hipSetDevice(c->device));
+    std::vector<uint4> info(std::max(n, 1u), make_uint4(0u, 1u, 1u, 0u));
+    size_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!tex[i].rgba8 || tex[i].width == 0 || tex[i].height == 0) return c->fail("texture " + std::to_string(i) + " is empty");
+        if ((uint64_t)tex[i].width * tex[i].height > (1ull << 28) || total + (size_t)tex[i].width * tex[i].height > 0xffffffffull) return c->fail("textures too large");
+        info[i] = make_uint4((uint32_t)total, tex[i].width, tex[i].height, 0u);
+        total += (size_t)tex[i].width * tex[i].height;
+    }
+    std::vector<uint32_t> texels(std::max<size_t>(total, 1), 0u);
+    for (uint32_t i = 0; i < n; i++) memcpy(&texels[info[i].x], tex[i].rgba8, (size_t)tex[i].width * tex[i].height * 4);
+    int rc = upload(c, c->texelBuf, texels.data(), texels.size() * 4);
+    if (rc) return rc;
+    if ((rc = upload(c, c->texInfoBuf, info.data(), info.size() * sizeof(uint4)))) return rc;
+    c->sc.texels = (const uint32_t*)c->texelBuf.p;
+    c->sc.texInfo = (const uint4*)c->texInfoBuf.p;
+    c->sc.texCount = n;
     return 0;
 }
 
@@ -596,9 +622,9 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
             wbox[2 * (size_t)i + 1] = make_float4(r.hi[0], r.hi[1], r.hi[2], 0.f);   // this saves are the cheap ones (profiles/README.md)
             boxOk = 4u;
         }
-        meta[i] = make_uint4(r.idx, r.cnt, o[i].materialIndex, (isIdent ? 1u : 0u) | boxOk);
+        meta[i] = make_uint4(r.idx, r.cnt, o[i].materialIndex, (isIdent ? 1u : 0u) | boxOk | ((o[i].samplerIndex & 0xffffu) << 16));
         {   // flags and root triangle count ride in the box's w components (one fetch per object in the skipping loop)
-            const uint32_t fl = meta[i].w, cn = r.cnt;
+            const uint32_t fl = meta[i].w & 0xffffu, cn = r.cnt;
             memcpy(&wbox[2 * (size_t)i].w, &fl, 4);
             memcpy(&wbox[2 * (size_t)i + 1].w, &cn, 4);
         }
@@ -661,6 +687,7 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
     c->boxPerRay = -1.0;  // a new scene: its ray cost is not known yet
     c->hostObjMat.clear(); c->hostObjRoot.clear(); c->hostSphereMat.clear(); c->hostMats.clear();
     c->sc.emitMode = 0; c->sc.emitCount = 0; c->sc.emitSphereMask = 0;
+    c->sc.texCount = 0;  // texture slots belong to the scene's materials: rt_upload_textures follows a new scene
     const uint32_t nNodes = s->bvhNodeCount, nTris = s->triangleCount;
 
     // ---- mesh segmentation: every distinct object.bvhIndex starts a mesh
@@ -776,6 +803,18 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
         }
     }
 
+    {   // vertex uvs (TrianglePoint: u in position.w, v in normal.w, src/vk_engine.h:64-67), 2 x float4 per triangle
+        std::vector<float4> tuv((size_t)std::max(nTris, 1u) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (uint32_t t = 0; t < nTris; t++) {
+            const Triangle& tr = s->triangles[t];
+            const TrianglePoint &p0 = s->triPoints[tr.v0], &p1 = s->triPoints[tr.v1], &p2 = s->triPoints[tr.v2];
+            tuv[2 * (size_t)t] = make_float4(p0.position[3], p0.normal[3], p1.position[3], p1.normal[3]);
+            tuv[2 * (size_t)t + 1] = make_float4(p2.position[3], p2.normal[3], 0.f, 0.f);
+        }
+        int rcu = upload(c, c->triUVBuf, tuv.data(), tuv.size() * sizeof(float4));
+        if (rcu) return rcu;
+        c->sc.triUV = (const float4*)c->triUVBuf.p;
+    }
     for (auto& b : c->sceneBufs) dev_free(b);
     c->sceneBufs.assign(5, DevBuf());
     int rc;

@@ -77,6 +77,13 @@ struct DevScene {
     // (or non-finite emission values): every light query is traversed in full, as round 1 did.
     const uint2* emitTris;
     uint32_t emitCount, emitSphereMask, emitMode;
+    // Textures: texels of all slots back to back (R8G8B8A8_SRGB, one uint32 per texel), texInfo[slot] =
+    // {first texel, width, height, -}, triUV = 2 x float4 per triangle {u0 v0 u1 v1} {u2 v2 - -} (cold: read per shaded hit of a
+    // textured material only). mats[3 m + 2].y carries albedoIndex, objMeta[].w bits 16.. the object's samplerIndex.
+    const uint32_t* texels;
+    const uint4* texInfo;
+    const float4* triUV;
+    uint32_t texCount;
     float cullOriginLimit;   // rays that start farther out than this (max |origin component|) skip nothing: the padding of the world-space
                              // boxes (1e-3 of an object's size and position) only dominates the slab tests' rounding, which grows with
                              // |origin|, while the origin is within 1e3 object scales (rt_update_objects)
@@ -873,7 +880,21 @@ struct FullHit {
     rt_vec3 hitPoint, normal;
     uint32_t materialIndex;
     bool frontFace;
+    float bu, bv, bw;   // the triangle test's u, v, w (raytrace.comp:238-240); unset for spheres
 };
+
+// hit.uv (raytrace.comp:249-256) and the albedo texel there; the declared texture semantics of include/rt_amd.h
+__device__ __forceinline__ rt_vec3 albedo_texel(const DevScene& sc, uint32_t slot, uint32_t tri, uint32_t obj, float bu, float bv, float bw) {
+    const float4 a = sc.triUV[2 * (size_t)tri], b = sc.triUV[2 * (size_t)tri + 1];  // {u0 v0 u1 v1} {u2 v2}
+    float u = (bw * a.x + bu * a.z) + bv * b.x, v = (bw * a.y + bu * a.w) + bv * b.y;
+    const bool e01 = a.x == a.z && a.y == a.w, e12 = a.z == b.x && a.w == b.y, e20 = b.x == a.x && b.y == a.y;
+    if (e01 || e12 || e20) { u = 0.5f; v = 0.5f; }
+    const uint4 ti = sc.texInfo[slot];
+    const bool clampEdge = ((sc.objMeta[obj].w >> 16) & 0xffffu) == 1u;
+    const uint32_t x = rt_tex_index(u, ti.y, clampEdge), y = rt_tex_index(v, ti.z, clampEdge);
+    const uint32_t t = sc.texels[(size_t)ti.x + (size_t)y * ti.y + x];
+    return rt_v3(rt_srgb8_to_linear(t & 0xffu), rt_srgb8_to_linear((t >> 8) & 0xffu), rt_srgb8_to_linear((t >> 16) & 0xffu));
+}
 
 __device__ __forceinline__ FullHit reconstruct_hit(const DevScene& sc, rt_vec3 ro, rt_vec3 rd, uint32_t obj, uint32_t tri) {
     FullHit f;
@@ -901,6 +922,7 @@ __device__ __forceinline__ FullHit reconstruct_hit(const DevScene& sc, rt_vec3 r
     f.hitPoint = xform_point_rows(m0, m1, m2, op);
     f.materialIndex = sc.objMeta[obj].z;
     f.frontFace = h.frontFace;
+    f.bu = h.u; f.bv = h.v; f.bw = h.w;
     return f;
 }
 
@@ -1112,6 +1134,8 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
                 diffuse = true;
                 refRays += 3;
                 rt_vec3 albedo = rt_v3(mA.x, mA.y, mA.z);
+                const uint32_t texSlot = __float_as_uint(mI.y);   // albedoIndex; 0xffffffff (-1) = none
+                if (texSlot < sc.texCount && !(obj & RT_HIT_SPHERE)) albedo = rt_mul(albedo, albedo_texel(sc, texSlot, hitTriIdx, obj, hit.bu, hit.bv, hit.bw));
                 rt_vec3 origin = rt_add(hit.hitPoint, rt_scale(hit.normal, 0.01f));
                 // lightSampleDir (:368-387)
                 float lx = rt_random(&state);

@@ -534,14 +534,15 @@ struct rt_scene : public RtSceneHost {
                     !parse_float(l.substr(s2 + 1, s3 - s2 - 1), c[1]) || !parse_float(l.substr(s3 + 1), c[2]))
                     return fail(filePath + ": bad " + prefix + " line");
                 for (int i = 0; i < 3; i++) cur.albedo[i] *= c[i];  // Ka and Kd both multiply (:1090-1100)
-            } else if (prefix == "map_Ka" || prefix == "map_Kd") {
-                cur.albedoIndex = (int)texturesUsed++;
-            } else if (prefix == "map_Ks") {
-                cur.metalnessIndex = (int)texturesUsed++;
-            } else if (prefix == "map_d") {
-                cur.alphaIndex = (int)texturesUsed++;
-            } else if (prefix == "map_bump") {  // case-sensitive: Blender's map_Bump is skipped
-                cur.bumpIndex = (int)texturesUsed++;
+            } else if (prefix == "map_Ka" || prefix == "map_Kd" || prefix == "map_Ks" || prefix == "map_d" || prefix == "map_bump") {
+                // path = directory of the MTL file + the rest of the line (:1110-1113); the slot is claimed in file order
+                // (map_bump is case-sensitive: Blender's map_Bump is skipped, as in the reference)
+                if (texturesUsed >= (uint32_t)RT_MAX_TEXTURES) return fail(filePath + ": more than RT_MAX_TEXTURES texture slots");
+                const size_t sp = l.find(' ');
+                const std::string value = sp == std::string::npos ? std::string() : l.substr(sp + 1);
+                texturePaths.push_back(filePath.substr(0, filePath.rfind('/') + 1) + value);
+                int& slot = (prefix == "map_Ks") ? cur.metalnessIndex : (prefix == "map_d") ? cur.alphaIndex : (prefix == "map_bump") ? cur.bumpIndex : cur.albedoIndex;
+                slot = (int)texturesUsed++;
             }
             // Ni, d are parsed and discarded; Ks, Ke, Ns, illum ignored (:1101-1108)
         }
@@ -708,6 +709,26 @@ int rt_scene_get_arrays(const rt_scene* s, RtSceneArrays* out) {
     out->triangles = s->triangles.data();    out->triangleCount = (uint32_t)s->triangles.size();
     out->objects = s->objects.data();        out->objectCount = (uint32_t)s->objects.size();
     out->bvhNodes = s->bvhNodes.data();      out->bvhNodeCount = (uint32_t)s->bvhNodes.size();
+    return 0;
+}
+
+uint32_t rt_scene_texture_count(const rt_scene* s) { return s ? (uint32_t)s->texturePaths.size() : 0u; }
+
+const char* rt_scene_texture_path(const rt_scene* s, uint32_t i) {
+    return (s && i < s->texturePaths.size()) ? s->texturePaths[i].c_str() : "";
+}
+
+int rt_scene_add_texture(rt_scene* s, const char* path) {
+    if (!s || !path) return -1;
+    if (s->texturesUsed >= (uint32_t)RT_MAX_TEXTURES) return s->fail("more than RT_MAX_TEXTURES texture slots");
+    s->texturePaths.push_back(path);
+    return (int)s->texturesUsed++;
+}
+
+int rt_scene_set_material(rt_scene* s, uint32_t i, const RayMaterial* m) {
+    if (!s || !m) return -1;
+    if (i >= s->rayMaterials.size()) return s->fail("material index out of range");
+    s->rayMaterials[i] = *m;
     return 0;
 }
 

@@ -24,6 +24,7 @@ struct RtSceneHost {
     std::vector<BVHNode> bvhNodes;
     uint32_t nodesUsed = 0;
     uint32_t texturesUsed = 0;
+    std::vector<std::string> texturePaths;   // image file of every claimed texture slot (imageFilePaths, src/vk_engine.cpp:1113)
     float sceneLo[3] = {1e30f, 1e30f, 1e30f};
     float sceneHi[3] = {-1e30f, -1e30f, -1e30f};
     std::unordered_map<std::string, int> loadedObjects;

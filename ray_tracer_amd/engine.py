@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _capi
 from ._capi import (BVHNode, PushConstants, RayMaterial, RenderObject, RtCounters, RtHit, RtPlacement,
-                    RtSceneArrays, Sphere, Triangle, TrianglePoint)
+                    RtSceneArrays, RtTexture, Sphere, Triangle, TrianglePoint)
 
 ASSET_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
 
@@ -150,6 +150,24 @@ class Scene:
             self._check(self._l.rt_scene_set_bvh_hook(self._h, fn, renderer._h), "rt_scene_set_bvh_hook")
         self._bvh_renderer = renderer  # keep it alive as long as the hook points at it
 
+    def texture_paths(self):
+        """Image file of every texture slot the MTL files (or add_texture) claimed, in slot order."""
+        n = self._l.rt_scene_texture_count(self._h)
+        return [os.fsdecode(self._l.rt_scene_texture_path(self._h, i)) for i in range(n)]
+
+    def add_texture(self, path):
+        """Claims the next texture slot for an image file; bind it through a material's albedoIndex."""
+        return self._check(self._l.rt_scene_add_texture(self._h, os.fsencode(path)), "add_texture")
+
+    def set_material(self, i, m):
+        self._check(self._l.rt_scene_set_material(self._h, int(i), C.byref(m)), "set_material")
+
+    def material(self, i):
+        a = self.arrays()
+        m = RayMaterial()
+        C.memmove(C.byref(m), C.byref(a.materials[i]), C.sizeof(RayMaterial))
+        return m
+
     def find_material(self, key):
         return self._l.rt_scene_find_material(self._h, key.encode())
 
@@ -224,6 +242,19 @@ class Renderer:
         self._check(self._l.rt_upload_scene(self._h, C.byref(a)), "rt_upload_scene")
         self._scene = scene
         self._counts = scene.counts()
+
+    def upload_textures(self, images):
+        """The scene's texture table: a list of uint8 arrays [h, w, 4] in slot order (rt_upload_textures); [] removes it."""
+        arr = (RtTexture * max(len(images), 1))()
+        keep = []
+        for i, im in enumerate(images):
+            im = np.ascontiguousarray(im, dtype=np.uint8)
+            if im.ndim != 3 or im.shape[2] != 4:
+                raise ValueError("textures are [height, width, 4] uint8 (RGBA)")
+            keep.append(im)
+            arr[i].width, arr[i].height = im.shape[1], im.shape[0]
+            arr[i].rgba8 = im.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._check(self._l.rt_upload_textures(self._h, arr, len(images)), "rt_upload_textures")
 
     def update_materials(self, scene):
         a = scene.arrays()
@@ -397,3 +428,14 @@ def hits_to_numpy(hits):
                 triHitIndex=u[:, 4].copy(), materialIndex=u[:, 5].copy(), frontFace=u[:, 6].copy(),
                 hitPoint=f[:, 7:10].copy(), normal=f[:, 10:13].copy(), boxTests=u[:, 13].copy(),
                 triTests=u[:, 14].copy())
+
+
+def load_textures(scene):
+    """Decodes the scene's texture files to RGBA8 the way the reference does (stbi_load(..., STBI_rgb_alpha),
+    src/vk_textures.cpp:103-113: 4 channels, rows top to bottom), with PIL. A missing file raises (the reference exits)."""
+    from PIL import Image
+    out = []
+    for path in scene.texture_paths():
+        with Image.open(path) as im:
+            out.append(np.asarray(im.convert("RGBA"), dtype=np.uint8))
+    return out

@@ -47,6 +47,9 @@ def build_parser():
     ap.add_argument("--obj-material", type=int, default=0, help="0 white 1 red 2 green 3 light 4 mirror 5 dielectric")
     ap.add_argument("--obj-scale", type=float, default=0.7)
     ap.add_argument("--obj-position", type=float, nargs=3, default=(0.0, 0.53, 0.0))
+    ap.add_argument("--obj-rotation", type=float, nargs=3, default=(0.0, 0.0, 0.0))
+    ap.add_argument("--obj-albedo-map", help="with --scene obj: an image bound as the albedo texture of the OBJ's materials "
+                                             "(what an MTL's map_Kd line does; dread.mtl has none, the author bound dread_alb.png by hand)")
     ap.add_argument("--width", type=int, default=1728)
     ap.add_argument("--height", type=int, default=1117)
     ap.add_argument("--device", type=int, default=0, help="GPU of a single-process run (one process per GPU uses LOCAL_RANK)")
@@ -80,7 +83,14 @@ def make_scene(args):
             raise SystemExit("--scene obj needs --obj FILE")
         s = engine.Scene()
         s.prepare_storage_buffers()
-        s.read_obj(args.obj, engine.placement(position=args.obj_position, scale=args.obj_scale, samplerIndex=1), args.obj_material)
+        n0 = s.counts()["materials"]
+        s.read_obj(args.obj, engine.placement(position=args.obj_position, scale=args.obj_scale, rotation=args.obj_rotation, samplerIndex=1), args.obj_material)
+        if args.obj_albedo_map:
+            slot = s.add_texture(args.obj_albedo_map)
+            for mi in range(n0, s.counts()["materials"]) or [args.obj_material]:
+                m = s.material(mi)
+                m.albedoIndex = slot
+                s.set_material(mi, m)
         return s, args.obj
     return scenes.CONFIGS[args.scene]()
 
@@ -137,6 +147,9 @@ def main(argv=None):
     pc = make_constants(args)
     r = engine.Renderer(device)
     r.upload_scene(scene)
+    paths = scene.texture_paths()
+    if paths and all(os.path.exists(p) for p in paths):   # the MTL files' maps (src/vk_engine.cpp:1155); absent files: untextured
+        r.upload_textures(engine.load_textures(scene))
     W, H = args.width, args.height
     tile = dict(row0=rank, rowStride=world) if world > 1 else {}
     t0 = time.perf_counter()

@@ -53,6 +53,8 @@ def _inputs(seed=11):
     x[13, 6] = 2.5; x[13, 0:3] = np.cross(x[13, 3:6], [1, 0, 0]) + 0.05 * x[13, 3:6]    # grazing: k < 0
     x[14, 7] = np.radians(25.0)                                                  # tan(fov / 2) of the default camera
     x[15, 7] = 1e-30; x[16, 7] = 1e-40                                           # tiny, subnormal
+    x[:, 15] = rng.integers(0, 256, N_PROBES)                                    # a texel byte
+    x[17, 7] = 1.0; x[18, 7] = -1.0 / 37; x[19, 7] = 36.0 / 37; x[20, 7] = 5.5; x[21, 7] = -7.25; x[22, 7] = 1e12   # texture coordinates
     return x
 
 
@@ -124,7 +126,7 @@ def _check_all(got, x):
         assert same.all(), f"slot {slot}: {int((~same).sum())} values differ, first at probe {np.argwhere(~same)[0].tolist()}"
     xs = x[:, 7].astype(np.float64)
     ys = x[:, 11].astype(np.float64)
-    fin = np.isfinite(xs)
+    fin = np.isfinite(xs) & (np.abs(xs) < 100.0)   # the polynomial sin / cos are defined for |x| < 8192; the shader stays within 2 pi
     with np.errstate(all="ignore"):
         # implementation-defined precision: against float64. GLSL 4.50 4.7.1 gives no bound for sin / cos / tan and a few ulp
         # for exp2 / log2 / pow; the bounds below are what the polynomial restatement achieves, with a little headroom.
@@ -151,6 +153,18 @@ def _check_all(got, x):
         gi = got[:, 38:54].reshape(-1, 4, 4).transpose(0, 2, 1).astype(np.float64)
         scale = np.abs(inv).max(axis=(1, 2), keepdims=True)
         assert (np.abs(gi - inv) <= 2e-6 * scale).all(), "inverse(mat4)"
+    # textures (the declared semantics of include/rt_amd.h): the sRGB transfer function and nearest-filter addressing
+    b = x[:, 15].astype(np.float64) / 255.0
+    lin = np.where(b <= 0.04045, b / 12.92, ((b + 0.055) / 1.055) ** 2.4)
+    err = np.abs(got[:, 54].astype(np.float64) - lin)
+    assert (err <= 8 * _ulp(lin) + 1e-9).all(), f"sRGB decode: worst {(err / _ulp(lin)).max()} ulp"
+    f = x[:, 7].astype(np.float32) * np.float32(37)
+    ok = np.isfinite(f) & (np.abs(f) < 2.0**30)
+    fl = np.floor(f[ok].astype(np.float64)).astype(np.int64)
+    assert np.array_equal(got[ok, 55].astype(np.int64), np.mod(fl, 37))           # VK_SAMPLER_ADDRESS_MODE_REPEAT
+    assert np.array_equal(got[ok, 56].astype(np.int64), np.clip(fl, 0, 36))       # CLAMP_TO_EDGE
+    assert (got[~ok, 55] == 0).all() and (got[~ok, 56] == 0).all()
+    assert got[17, 55] == 0 and got[17, 56] == 36 and got[18, 55] == 36 and got[18, 56] == 0   # u = 1 wraps to 0 / clamps to the last texel
     # named edge cases
     assert got[0, 8] == 0 and got[1, 8] == 0                                     # sign(+-0) = 0
     assert np.isnan(got[5, 9:12]).all()                                          # normalize(0) = NaN
