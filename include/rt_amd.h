@@ -277,8 +277,10 @@ int  rt_upload_scene(rt_ctx* ctx, const RtSceneArrays* scene);
  * table, as R8G8B8A8_SRGB texels, rows top to bottom (what stbi_load(..., STBI_rgb_alpha) returns). The snapshot's shader
  * computes hit.uv (raytrace.comp:249-256) and never samples; the semantics here are this build's declared choice
  * ("parity unpinned"): a triangle hit whose material has albedoIndex >= 0 multiplies the material's albedo by
- * the texel at hit.uv — nearest filter, sampler RenderObject.samplerIndex (0 = repeat, 1 = clamp to edge, :525-531),
- * sRGB -> linear. Borrowed for the call; n = 0 removes all textures. */
+ * the texel at (u, 1 - v) of hit.uv — OBJ's v runs upwards, the image's rows downwards; with the flip dread.obj shows its
+ * plate, bolts and wheels where the reference's renders/dread_texture.png has them — nearest filter, sampler
+ * RenderObject.samplerIndex (0 = repeat, 1 = clamp to edge, :525-531), sRGB -> linear. Spheres are not textured.
+ * Borrowed for the call; n = 0 removes all textures. */
 typedef struct RtTexture {
     uint32_t width, height;
     const uint8_t* rgba8;   /* width * height * 4 bytes */

@@ -332,7 +332,7 @@ rt_vec3 albedoTexel(const Scene& sc, const HitInfo& hit, const RayMaterial& m) {
     if (m.albedoIndex < 0 || (size_t)m.albedoIndex >= g_textures.size() || hit.isSphere) return rt_v3(1.f, 1.f, 1.f);
     const OracleTexture& t = g_textures[(size_t)m.albedoIndex];
     const bool clampEdge = sc.a.objects[hit.objectHitIndex].samplerIndex == 1u;
-    const uint32_t x = rt_tex_index(hit.uv[0], t.width, clampEdge), y = rt_tex_index(hit.uv[1], t.height, clampEdge);
+    const uint32_t x = rt_tex_index(hit.uv[0], t.width, clampEdge), y = rt_tex_index(1.f - hit.uv[1], t.height, clampEdge);
     const uint8_t* px = &t.rgba[((size_t)y * t.width + x) * 4];
     return rt_v3(rt_srgb8_to_linear(px[0]), rt_srgb8_to_linear(px[1]), rt_srgb8_to_linear(px[2]));
 }

@@ -883,7 +883,7 @@ struct FullHit {
     float bu, bv, bw;   // the triangle test's u, v, w (raytrace.comp:238-240); unset for spheres
 };
 
-// hit.uv (raytrace.comp:249-256) and the albedo texel there; the declared texture semantics of include/rt_amd.h
+// hit.uv (raytrace.comp:249-256) and the albedo texel at (u, 1 - v); the declared texture semantics of include/rt_amd.h
 __device__ __forceinline__ rt_vec3 albedo_texel(const DevScene& sc, uint32_t slot, uint32_t tri, uint32_t obj, float bu, float bv, float bw) {
     const float4 a = sc.triUV[2 * (size_t)tri], b = sc.triUV[2 * (size_t)tri + 1];  // {u0 v0 u1 v1} {u2 v2}
     float u = (bw * a.x + bu * a.z) + bv * b.x, v = (bw * a.y + bu * a.w) + bv * b.y;
@@ -891,7 +891,7 @@ __device__ __forceinline__ rt_vec3 albedo_texel(const DevScene& sc, uint32_t slo
     if (e01 || e12 || e20) { u = 0.5f; v = 0.5f; }
     const uint4 ti = sc.texInfo[slot];
     const bool clampEdge = ((sc.objMeta[obj].w >> 16) & 0xffffu) == 1u;
-    const uint32_t x = rt_tex_index(u, ti.y, clampEdge), y = rt_tex_index(v, ti.z, clampEdge);
+    const uint32_t x = rt_tex_index(u, ti.y, clampEdge), y = rt_tex_index(1.f - v, ti.z, clampEdge);
     const uint32_t t = sc.texels[(size_t)ti.x + (size_t)y * ti.y + x];
     return rt_v3(rt_srgb8_to_linear(t & 0xffu), rt_srgb8_to_linear((t >> 8) & 0xffu), rt_srgb8_to_linear((t >> 16) & 0xffu));
 }
