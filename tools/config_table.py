@@ -27,14 +27,23 @@ for name, key, W, H, spp, per in CONFIGS:
         spp = max(per if per < 8 else 8, spp // 8)
         per = min(per, spp)
     r.upload_scene(scene)
+    pcw = cam(W, H, raysPerPixel=1, progressive=1, singleRender=0)
+    r.render(pcw, W, H)   # the first dispatch of a scene measures its rays (launch parameters follow the ray length)
+    r.render(pcw, W, H)
     for world in (1, 2, 4, 8):
         pc = cam(W, H, raysPerPixel=per, progressive=1, singleRender=0)
         r.reset_counters()
         r.sync()
         t = time.perf_counter()
-        for i in range(spp // per):
+        i, n = 0, spp // per
+        while i < n:   # one of N GPUs keeps N dispatches (progressive frames) in flight: rt_render_frames
+            k = min(world, n - i)
             pc.frameCount = i
-            r.render(pc, W, H, row0=0, rowStride=world, sync=False)
+            if k == 1:
+                r.render(pc, W, H, row0=0, rowStride=world, sync=False)
+            else:
+                r.render_frames(pc, W, H, k, row0=0, rowStride=world, sync=False)
+            i += k
         r.sync()
         dt = time.perf_counter() - t
         c = r.counters()

@@ -39,6 +39,38 @@ __global__ void kB(const float4* __restrict__ tab, const uint32_t* __restrict__ 
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
+// A with only the first `active` lanes of every wave switched on: does the vector memory pipeline charge a load by the
+// lanes that take part, or by the wave instruction? (trace_wave's interior step runs with ~35 of 64 lanes)
+__global__ void kAm(const float4* __restrict__ tab, const uint32_t* __restrict__ idx, int iters, uint32_t mask, float* out, uint32_t active) {
+    uint32_t i = idx[blockIdx.x * blockDim.x + threadIdx.x];
+    float acc = 0.f;
+    // active < 100: the first `active` lanes; 100 + k: every k-th lane (scattered over all quads); 200 + p: a pseudo-random p % of the lanes
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool on = active < 100u ? lane < active : active < 200u ? (lane % (active - 100u)) == 0u : ((lane * 2654435761u + blockIdx.x * 40503u) >> 16) % 100u < active - 200u;
+    if (on) {
+        for (int it = 0; it < iters; it++) {
+            const float4* p = tab + 4 * (size_t)i;
+            float4 a = p[0], b = p[1], c = p[2], d = p[3];
+            acc += a.x + b.y + c.z + d.w;
+            i = (__float_as_uint(d.w) ^ (i * 2654435761u)) & mask;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+// C: four lanes per record, ONE load instruction per record (lane j of a quad reads bytes 16 j .. 16 j + 15): the fetch of a
+// "four lanes per ray" traversal. A wave instruction serves 16 records.
+__global__ void kC(const float4* __restrict__ tab, const uint32_t* __restrict__ idx, int iters, uint32_t mask, float* out) {
+    uint32_t i = idx[(blockIdx.x * blockDim.x + threadIdx.x) >> 2];
+    const uint32_t j = threadIdx.x & 3u;
+    float acc = 0.f;
+    for (int it = 0; it < iters; it++) {
+        const float4 v = tab[4 * (size_t)i + j];
+        acc += v.x;
+        const uint32_t w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v.w), 0xff, 0xf, 0xf, true);  // lane 3's word to the quad
+        i = (w ^ (i * 2654435761u)) & mask;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
 int main() {
     const uint32_t nrec = 1u << 18;  // 16 MiB of 64-B records
     std::vector<float> h((size_t)nrec * 16);
@@ -62,6 +94,28 @@ int main() {
             if (rep) printf("footprint %8u B: A (lane-private 4x16B) %7.3f ms = %6.1f Grec/s %6.2f TB/s | B (quad-coalesced) %7.3f ms = %6.1f Grec/s %6.2f TB/s\n",
                             (mask + 1) * 64, msA, recs / msA / 1e6, recs * 64 / msA / 1e9, msB, recs / msB / 1e6, recs * 64 / msB / 1e9);
         }
+    }
+    // lanes taking part in A's loads, and the one-load-per-record quad fetch (table in L2: 2 MB)
+    {
+        const uint32_t mask = (1u << 15) - 1;
+        for (uint32_t active : {64u, 48u, 32u, 16u, 8u, 102u, 104u, 108u, 275u, 250u, 225u}) {
+            float ms = 0;
+            for (int rep = 0; rep < 2; rep++) {
+                hipEventRecord(e0); kAm<<<blocks, threads>>>(tab, idx, iters, mask, out, active); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            }
+            const double winstr = (double)n / 64 * iters * 4;  // wave-level load instructions
+            const double frac = active < 100u ? active / 64.0 : active < 200u ? 1.0 / (active - 100u) : (active - 200u) / 100.0;
+            printf("A, lanes %3u (%s, %.0f %% active): %7.3f ms, %6.1f Grec/s, %5.2f ns per wave-level load on a CU (%.1f clocks at 2.4 GHz)\n", active,
+                   active < 100u ? "first n" : active < 200u ? "every k-th" : "random", frac * 100, ms,
+                   (double)n * frac * iters / ms / 1e6, ms * 1e6 / (winstr / 256), ms * 1e6 / (winstr / 256) * 2.4);
+        }
+        float ms = 0;
+        for (int rep = 0; rep < 2; rep++) {
+            hipEventRecord(e0); kC<<<blocks, threads>>>(tab, idx, iters, mask, out); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        }
+        const double winstr = (double)n / 64 * iters;
+        printf("C, four lanes per record, one load each: %7.3f ms, %6.1f Grec/s, %5.2f ns per wave-level load on a CU (%.1f clocks)\n", ms,
+               (double)n / 4 * iters / ms / 1e6, ms * 1e6 / (winstr / 256), ms * 1e6 / (winstr / 256) * 2.4);
     }
     return 0;
 }
