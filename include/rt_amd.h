@@ -333,6 +333,9 @@ int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
  *                    closest hit is emissive and how far it is (raytrace.comp:389-403,443-460), are answered from the list of
  *                    emissive primitives where that is possible and stop at the first hit that answers them; 0: every one of
  *                    them is a full closest-hit traversal. Same pixels either way.
+ *   "camera_reuse"   1 (default): the samples of a pixel all start with the same camera ray (the shader does not jitter,
+ *                    raytrace.comp:541-557,571-573), so its hit is kept from the first sample and the later samples of the
+ *                    dispatch start from it without a traversal; 0: traced every time. Off for the debug heat maps.
  *   "pipeline"       -1 (default) pick by tile size, 0 = multi-kernel wavefront pipeline
  *                    (k_trace_pw + k_shade per round), 1 = wave-private fused pipeline
  *                    (k_render_fused: every wave runs the stages on its own 8x8 pixel blocks)

@@ -62,6 +62,8 @@ def lib():
                                         C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(RtHit)]
         l.oracle_set_light_queries.restype = None
         l.oracle_set_light_queries.argtypes = [C.c_int]
+        l.oracle_set_camera_reuse.restype = None
+        l.oracle_set_camera_reuse.argtypes = [C.c_int]
         l.oracle_set_textures.restype = None
         l.oracle_set_textures.argtypes = [C.POINTER(RtTexture), C.c_uint32]
         l.oracle_random.restype = C.c_float

@@ -327,6 +327,7 @@ float emitter_min_t(const Scene& sc, const Ray& ray, uint64_t& tested) {
 // (0 repeat, 1 clamp to edge, src/vk_engine.cpp:525-531), R8G8B8A8_SRGB decoded to linear. Parity unpinned.
 struct OracleTexture { uint32_t width, height; std::vector<uint8_t> rgba; };
 std::vector<OracleTexture> g_textures;
+bool g_cameraReuse = true;   // mirrors rt_set_tuning("camera_reuse", v): only the executed-work counters depend on it
 
 rt_vec3 albedoTexel(const Scene& sc, const HitInfo& hit, const RayMaterial& m) {
     if (m.albedoIndex < 0 || (size_t)m.albedoIndex >= g_textures.size() || hit.isSphere) return rt_v3(1.f, 1.f, 1.f);
@@ -441,7 +442,7 @@ BxDFResult dielectricBTDF(PathCtx& c, const rt_vec3& incoming, const HitInfo& pr
 }
 
 // raytrace.comp:483-537
-rt_vec3 trace(PathCtx& c, Ray ray, uint32_t& state, Tally& mainStats) {
+rt_vec3 trace(PathCtx& c, Ray ray, uint32_t& state, Tally& mainStats, uint32_t sampleIndex) {
     rt_vec3 totalColor = rt_v3(0.f, 0.f, 0.f);
     rt_vec3 attenuation = rt_v3(1.f, 1.f, 1.f);
     rt_vec3 directLight = rt_v3(0.f, 0.f, 0.f);
@@ -455,7 +456,9 @@ rt_vec3 trace(PathCtx& c, Ray ray, uint32_t& state, Tally& mainStats) {
         HitInfo hit = calculateIntersections(c.sc, newRay, t, &c.tot.stackOverflow);
         mainStats.box += t.box; mainStats.tri += t.tri;
         tally_ref(c, t, hit);
-        tally_unique(c, t, hit);
+        // the pipeline keeps the camera ray's hit from a pixel's first sample (every sample starts with the same ray, :541-557):
+        // the first segment of the later samples is not traversed again (not so for the heat maps, which count per pixel)
+        if (!(j == 0 && sampleIndex > 0 && g_cameraReuse && c.pc.rayTraceParams.debug < 0)) tally_unique(c, t, hit);
         c.tot.segments++;
         if (hit.didHit) {
             const RayMaterial& m = c.sc.a.materials[hit.materialIndex];
@@ -534,7 +537,7 @@ void pixel_main(PathCtx& c, uint32_t gx, uint32_t gy, uint32_t W, uint32_t H, fl
     Tally stats;
     rt_vec3 outColor = rt_v3(0.f, 0.f, 0.f);
     uint32_t samples = td.singleRender ? td.sampleLimit : td.raysPerPixel;
-    for (uint32_t i = 0; i < samples; i++) outColor = rt_add(outColor, trace(c, ray, state, stats));
+    for (uint32_t i = 0; i < samples; i++) outColor = rt_add(outColor, trace(c, ray, state, stats, i));
     float fs = (float)samples;
     outColor = rt_v3(outColor.x / fs, outColor.y / fs, outColor.z / fs);
 
@@ -627,6 +630,8 @@ void oracle_set_textures(const RtTexture* tex, uint32_t n) {
         g_textures.push_back(std::move(t));
     }
 }
+
+void oracle_set_camera_reuse(int on) { g_cameraReuse = on != 0; }
 
 // mirrors rt_set_tuning("light_queries", v): which definition of "executed work" the counters follow (pixels never change)
 void oracle_set_light_queries(int on) { g_lightQueries = on != 0; }

@@ -30,6 +30,7 @@ int oracle_render(const RtSceneArrays* scene, const PushConstants* pc, uint32_t 
 int oracle_trace_rays(const RtSceneArrays* scene, uint32_t sphereCount, uint32_t objectCount, uint32_t n,
                       const float* origins, const float* dirs, RtHit* out);
 void oracle_set_light_queries(int on);
+void oracle_set_camera_reuse(int on);
 void oracle_set_textures(const RtTexture* textures, uint32_t n);
 float oracle_random(uint32_t* state);
 void oracle_math_probe(float x, float y, float out[8]);

@@ -52,6 +52,7 @@ struct rt_ctx {
     int commRanks = 0, commRank = 0;
     DevBuf gatherBuf;
     int framesPerLaunch = 0; // rt_render_frames: most frames of a tile rendered by one launch (0 = as many as fit)
+    int cameraReuse = 1;    // rt_set_tuning("camera_reuse", 0): trace the camera ray of every sample
     int lightQueries = 1;   // rt_set_tuning("light_queries", 0): trace every NEE ray and cosine probe in full
     uint32_t maxLeafDepth = 0;
     std::vector<uint32_t> nodeRemap;          // reference node index -> device node index
@@ -172,7 +173,7 @@ int ensure_state(rt_ctx* c, uint32_t nPixels) {
     if (c->capacity >= nPixels && c->stateBuf.p) return 0;
     const size_t stride4 = (((size_t)nPixels * 16) + 255) & ~(size_t)255;  // bytes per float4 array
     const size_t stride1 = (((size_t)nPixels * 4) + 255) & ~(size_t)255;
-    const int nF4 = 13, nU1 = 2;
+    const int nF4 = 14, nU1 = 2;
     int rc = dev_alloc(c, c->stateBuf, stride4 * nF4 + stride1 * nU1);
     if (rc) return rc;
     PathState& ps = c->ps;
@@ -952,6 +953,7 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
     fp.progressive = td.progressive;
     fp.frameCount = pc->frameCount;
     fp.nFrames = nFrames;
+    fp.camReuse = (c->cameraReuse && td.debug < 0) ? 1u : 0u;
     fp.debug = td.debug;
     fp.boxCap = td.boxCap;
     fp.triCap = td.triangleCap;
@@ -1223,6 +1225,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     if (k == "pipeline") { if (value < -1 || value > 1) return c->fail("pipeline: -1 (auto), 0 or 1"); c->pipeline = value; }
     else if (k == "probe") { c->probe = value ? 1 : 0; }
     else if (k == "frames_per_launch") { if (value < 0) return c->fail("frames_per_launch >= 0"); c->framesPerLaunch = value; }
+    else if (k == "camera_reuse") { c->cameraReuse = value ? 1 : 0; }
     else if (k == "light_queries") { c->lightQueries = value ? 1 : 0; int rc = rebuild_emitters(c); if (rc) return rc; }
     else if (k == "fused_below_box_tests") { if (value < 0) return c->fail("fused_below_box_tests >= 0"); c->fusedBelowBoxTests = (uint32_t)value; }
     else if (k == "fused_below_pixels") { if (value < 0) return c->fail("fused_below_pixels >= 0"); c->fusedBelowPixels = (uint32_t)value; }

@@ -113,8 +113,9 @@ struct PathState {
     __host__ __device__ __forceinline__ float4* direct() const { return arr(10); }     // directLight
     __host__ __device__ __forceinline__ float4* pendAlbedo() const { return arr(11); } // albedo of the previous diffuse hit
     __host__ __device__ __forceinline__ float4* accum() const { return arr(12); }      // sum of trace() over the pixel's samples (:572)
-    __host__ __device__ __forceinline__ uint32_t* statBox() const { return (uint32_t*)arr(13); }             // stats[0] of the pixel (main-path traversals only)
-    __host__ __device__ __forceinline__ uint32_t* statTri() const { return (uint32_t*)arr(13) + pitchStat; } // stats[1]
+    __host__ __device__ __forceinline__ float4* camHit() const { return arr(13); }     // the camera ray's hit record, kept from the pixel's first sample (FrameParams::camReuse)
+    __host__ __device__ __forceinline__ uint32_t* statBox() const { return (uint32_t*)arr(14); }             // stats[0] of the pixel (main-path traversals only)
+    __host__ __device__ __forceinline__ uint32_t* statTri() const { return (uint32_t*)arr(14) + pitchStat; } // stats[1]
 };
 
 struct Queues {
@@ -134,6 +135,9 @@ struct FrameParams {
     uint32_t startingSeed;  // uint(random(frameCount) * 23892183)
     uint32_t samples, bounceLimit;
     uint32_t progressive, frameCount;
+    uint32_t camReuse;      // every sample of a pixel starts with the same camera ray (no jitter, raytrace.comp:541-557,571-573): its hit is
+                            // kept from the first sample and samples 2.. start from it without a traversal (off for the heat maps,
+                            // which count every traversal's tests per pixel)
     uint32_t nFrames;       // > 1: this launch renders that many consecutive progressive frames of the tile at once (rt_render_frames).
                             // Slots then run over {64 tile slots} x {frames}: slot = (tile slot / 64) * 64 * nFrames + frame * 64 +
                             // tile slot % 64 (frame_slot), so that the waves in flight work on one region of the tile in all its
@@ -1044,8 +1048,9 @@ struct ShadeArgs {
 
 // One path, one segment: trace()'s loop body (raytrace.comp:495-534) with diffuseBRDF split around the
 // probe rays, plus main()'s sample loop (:571-573). Reads the hit records of the path's rays, writes
-// its next rays. Outputs: alive (a main ray was emitted), auxMask (bit 0: the NEE ray, bit 1: the cosine probe of this
-// diffuse bounce have to be traced; a light query that emitter_min_t answers is not), refRays (the shader's
+// its next rays. Outputs: alive (the path, or the pixel's next sample, goes on), auxMask (bit 0: the NEE ray, bit 1: the cosine probe
+// of this diffuse bounce have to be traced — a light query that emitter_min_t answers is not; bit 2: the main ray needs no
+// traversal, its hit record is already there: the kept camera hit), refRays (the shader's
 // calculateIntersections calls for this segment), nPaths (1 if a sample finished), emitTests (primitives emitter_min_t tested).
 __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& ps, const FrameParams& fp, uint32_t slot, bool& alive,
                                            uint32_t& auxMask, uint32_t& refRays, uint32_t& nPaths, uint32_t& emitTests, bool withMask = true) {
@@ -1066,6 +1071,7 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
     const uint32_t obj = __float_as_uint(hM.y);
     const uint32_t hitTriIdx = __float_as_uint(hM.z);
     refRays = 1;  // this segment's calculateIntersections (raytrace.comp:496)
+    if (fp.camReuse && j == 0u && samplesDone == 0u) ps.camHit()[slot] = hM;  // the camera ray's hit, for the pixel's later samples
 
     bool done = false;       // this sample's trace() returned
     bool zeroed = false;     // ... through the NaN/negative early-out (:505)
@@ -1217,7 +1223,13 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
     }
 
     if (alive) {
-        ps.hit(RAY_MAIN)[slot] = sphere_seed(sc, ro, rd, withMask);
+        if (done && fp.camReuse) {
+            // a new sample of the same pixel: the same camera ray, whose hit is known — no traversal this round (bit 2)
+            ps.hit(RAY_MAIN)[slot] = ps.camHit()[slot];
+            auxMask |= 4u;
+        } else {
+            ps.hit(RAY_MAIN)[slot] = sphere_seed(sc, ro, rd, withMask);
+        }
         if (wantAux) {
             float4 sL = sphere_seed(sc, auxOrigin, auxL, withMask), sC = sphere_seed(sc, auxOrigin, auxC, withMask);
             auxMask = 3u;
@@ -1263,20 +1275,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
     // Queue compaction: ranks inside a wave from ballots, wave offsets through LDS, and ONE atomic
     // per block and queue (a single hot counter saturates near 90 atomics/us; per-wave atomics made
     // this kernel wait on them for half of its run time).
-    const unsigned long long mAlive = __ballot(alive);
+    const unsigned long long mAlive = __ballot(alive), mM = __ballot(alive && !(auxMask & 4u));
     const unsigned long long mL = __ballot(alive && (auxMask & 1u)), mC = __ballot(alive && (auxMask & 2u));
-    const uint32_t nAlive = __popcll(mAlive), nL = __popcll(mL), nC = __popcll(mC);
+    const uint32_t nAlive = __popcll(mAlive), nM = __popcll(mM), nL = __popcll(mL), nC = __popcll(mC);
     const uint32_t wRef = wave_sum_u32(refRays), wPaths = wave_sum_u32(nPaths), wSeg = wave_sum_u32(live ? 1u : 0u), wEmit = wave_sum_u32(emitTests);
     const uint32_t wv = threadIdx.x / RT_WAVE;
     if (lane_id() == 0) {
-        s_cnt[wv][0] = nAlive; s_cnt[wv][1] = nL + nC; s_cnt[wv][2] = wRef; s_cnt[wv][3] = wPaths; s_cnt[wv][4] = wSeg; s_cnt[wv][5] = wEmit;
+        s_cnt[wv][0] = nAlive; s_cnt[wv][1] = nM + nL + nC; s_cnt[wv][2] = wRef; s_cnt[wv][3] = wPaths; s_cnt[wv][4] = wSeg; s_cnt[wv][5] = wEmit;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tA = 0, tX = 0, tRef = 0, tP = 0, tS = 0, tE = 0;
-        for (int w = 0; w < RT_BLOCK / RT_WAVE; w++) { tA += s_cnt[w][0]; tX += s_cnt[w][1]; tRef += s_cnt[w][2]; tP += s_cnt[w][3]; tS += s_cnt[w][4]; tE += s_cnt[w][5]; }
+        uint32_t tA = 0, tR = 0, tRef = 0, tP = 0, tS = 0, tE = 0;
+        for (int w = 0; w < RT_BLOCK / RT_WAVE; w++) { tA += s_cnt[w][0]; tR += s_cnt[w][1]; tRef += s_cnt[w][2]; tP += s_cnt[w][3]; tS += s_cnt[w][4]; tE += s_cnt[w][5]; }
         s_base[0] = tA ? atomicAdd(sa.outActiveCount, tA) : 0u;
-        s_base[1] = tA ? atomicAdd(sa.outRayCount, tA + tX) : 0u;
+        s_base[1] = tR ? atomicAdd(sa.outRayCount, tR) : 0u;
         atomicAdd(&sa.counters->raysReference, (unsigned long long)tRef);
         atomicAdd(&sa.counters->paths, (unsigned long long)tP);
         atomicAdd(&sa.counters->segments, (unsigned long long)tS);
@@ -1285,13 +1297,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
     __syncthreads();
     if (alive) {
         uint32_t baseA = s_base[0], baseR = s_base[1];
-        for (uint32_t w = 0; w < wv; w++) { baseA += s_cnt[w][0]; baseR += s_cnt[w][0] + s_cnt[w][1]; }
-        const uint32_t rk = lanes_below(mAlive);
-        sa.outActive[baseA + rk] = slot;
+        for (uint32_t w = 0; w < wv; w++) { baseA += s_cnt[w][0]; baseR += s_cnt[w][1]; }
+        sa.outActive[baseA + lanes_below(mAlive)] = slot;
         // per wave: main rays first, then its NEE rays, then its cosine probes
-        sa.outRays[baseR + rk] = (slot << 2) | RAY_MAIN;
-        if (auxMask & 1u) sa.outRays[baseR + nAlive + lanes_below(mL)] = (slot << 2) | RAY_NEE;
-        if (auxMask & 2u) sa.outRays[baseR + nAlive + nL + lanes_below(mC)] = (slot << 2) | RAY_PROBE;
+        if (!(auxMask & 4u)) sa.outRays[baseR + lanes_below(mM)] = (slot << 2) | RAY_MAIN;
+        if (auxMask & 1u) sa.outRays[baseR + nM + lanes_below(mL)] = (slot << 2) | RAY_NEE;
+        if (auxMask & 2u) sa.outRays[baseR + nM + nL + lanes_below(mC)] = (slot << 2) | RAY_PROBE;
     }
 }
 
@@ -1464,14 +1475,15 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
             if (exhausted) break;
             continue;
         }
+        const unsigned long long mM = __ballot(alive && !(auxMask & 4u));  // bit 2: the kept camera hit stands in for the main ray
         const unsigned long long mL = __ballot(alive && (auxMask & 1u)), mC = __ballot(alive && (auxMask & 2u));
-        const uint32_t nA = __popcll(mA), nL = __popcll(mL), nC = __popcll(mC);
+        const uint32_t nM = __popcll(mM), nL = __popcll(mL), nC = __popcll(mC);
         if (alive) {
-            list[lanes_below(mA)] = (slot << 2) | RAY_MAIN;
-            if (auxMask & 1u) list[nA + lanes_below(mL)] = (slot << 2) | RAY_NEE;
-            if (auxMask & 2u) list[nA + nL + lanes_below(mC)] = (slot << 2) | RAY_PROBE;
+            if (!(auxMask & 4u)) list[lanes_below(mM)] = (slot << 2) | RAY_MAIN;
+            if (auxMask & 1u) list[nM + lanes_below(mL)] = (slot << 2) | RAY_NEE;
+            if (auxMask & 2u) list[nM + nL + lanes_below(mC)] = (slot << 2) | RAY_PROBE;
         }
-        const uint32_t nRays = nA + nL + nC;
+        const uint32_t nRays = nM + nL + nC;
         __threadfence_block();  // the rays written by shade_path / init_path are read by other lanes of this wave
         trace_wave<STACK, OVF, PIX, false, true, CULL>(sc, ps, ta, stack, ovf, ovfStride, list, nRays, wt);
         __threadfence_block();  // ... and so are the hit records
@@ -1485,9 +1497,12 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
             segTot++;
             if (CULL && nowAlive && nBox) {
                 // the new rays' object masks (sphere_seed), here rather than inside shade_path: its registers are spilling already
-                float4 sd = ps.hit(RAY_MAIN)[slot];
-                sd.z = __uint_as_float(reach_mask_from(s_box, nBox, f4xyz(ps.rayO()[slot]), f4xyz(ps.rayD()[slot]), sc.cullOriginLimit));
-                ps.hit(RAY_MAIN)[slot] = sd;
+                float4 sd;
+                if (!(auxMask & 4u)) {
+                    sd = ps.hit(RAY_MAIN)[slot];
+                    sd.z = __uint_as_float(reach_mask_from(s_box, nBox, f4xyz(ps.rayO()[slot]), f4xyz(ps.rayD()[slot]), sc.cullOriginLimit));
+                    ps.hit(RAY_MAIN)[slot] = sd;
+                }
                 if (auxMask & 1u) {
                     sd = ps.hit(RAY_NEE)[slot];
                     sd.z = __uint_as_float(reach_mask_from(s_box, nBox, f4xyz(ps.auxO()[slot]), f4xyz(ps.auxDL()[slot]), sc.cullOriginLimit));
