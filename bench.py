@@ -53,9 +53,9 @@ def main():
                     help="send a one-rank job through the process group, gather and reductions too (RCCL smoke test on a one-GPU box)")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole frame alone and compares it with the gathered one")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="steps (= progressive frames) a rank submits at once through rt_render_frames; 0 = as many as give the rank "
-                         "a full frame's worth of pixels (1 on one GPU, N on N GPUs: a 1/N tile has too few pixels to fill a GPU, "
-                         "because a pixel's samples are serial), 1 = every step its own dispatch and its own gather")
+                    help="steps (= progressive frames) a rank submits at once through rt_render_frames; 0 = N on N GPUs (a 1/N tile "
+                         "has too few pixels to fill a GPU, because a pixel's samples are serial; N frames of it do) and 2 on one GPU "
+                         "(the second frame's pixels fill the first one's tail: -2.6 %), 1 = every step its own dispatch and its own gather")
     args = ap.parse_args()
 
     import numpy as np
@@ -113,7 +113,7 @@ def main():
     # Steps are progressive frames: independent until they are blended in order. A rank may therefore submit a group of
     # them at once (rt_render_frames: their pixels share a launch, the blends follow in frame order — the same bits as
     # one dispatch per step); the strips are gathered once per group.
-    fif = args.frames_in_flight if args.frames_in_flight > 0 else world
+    fif = args.frames_in_flight if args.frames_in_flight > 0 else max(world, 2)
 
     def launch(i, n):
         pc.frameCount = i
@@ -188,7 +188,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} ({label}), {W}x{H}, {args.spp} spp/step, bounceLimit 8, "
-                                   f"rows interleaved over {world} GPU(s)" + (f", {fif} steps in flight per rank, one RCCL gather per group" if world > 1 else ""),
+                                   f"rows interleaved over {world} GPU(s)" + f", {fif} steps in flight per rank" + (", one RCCL gather per group" if world > 1 else ""),
                        "scene": args.scene, "assets": label, "width": W, "height": H, "spp_per_step": args.spp, "frames_in_flight": fif,
                        "pipeline": ["multi-kernel (k_trace_pw + k_shade per round)", "fused (k_render_fused)"][r.last_pipeline()]},
             "unique_mrays_per_s": tot["raysTraced"] / dt / 1e6,

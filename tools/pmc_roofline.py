@@ -91,7 +91,9 @@ def main():
         res["l1_lookups_per_launch"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"]
     if bench:
         steps = max(bench.get("steps", 1), 1)
-        res["rays_traced_per_launch"] = bench["unique_mrays_per_s"] * 1e6 * bench["ms_per_step"] * 1e-3
+        launches = max(bench.get("roofline", {}).get("launches") or steps, 1)   # a launch may render several steps (frames in flight)
+        res["steps_per_launch"] = steps / launches
+        res["rays_traced_per_launch"] = bench["unique_mrays_per_s"] * 1e6 * bench["ms_per_step"] * 1e-3 * steps / launches
         res["box_tests_per_ray"] = bench.get("box_tests_per_ray")
         if "l1_lookups_per_launch" in res:
             res["l1_lookups_per_ray"] = res["l1_lookups_per_launch"] / res["rays_traced_per_launch"]

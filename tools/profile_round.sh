@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p $out
-CMD="python3 bench.py --steps 3 --warmup 1 --spp 8 $*"
+CMD="python3 bench.py --steps 4 --warmup 2 --spp 8 --tune probe=0 $*"   # even counts: every launch renders two steps (frames in flight); no ray-cost probe (a 1.6 ms launch of the same kernel would sit in the per-kernel averages; the warm-up measures the ray cost instead)
 timeout -k 10 400 $CMD > $out/bench.log 2>&1 || { tail -5 $out/bench.log; exit 1; }
 grep '^{' $out/bench.log | tail -1 > $out/bench.json
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD --cpu-seconds 0 > $out/bench_under_rocprof.log 2>&1 || { tail -5 $out/bench_under_rocprof.log; exit 1; }
@@ -17,9 +17,9 @@ kern=$(python3 -c "import json; print('k_render_fused' if 'fused' in json.load(o
 i=0
 for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_FLAT_READ_WAVEFRONTS_sum"; do
   i=$((i+1))
-  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc/pass_$i -- $CMD --cpu-seconds 0 --no-profile > $out/pmc_$i.log 2>&1 || { echo "pmc pass $i ($set) failed"; tail -5 $out/pmc_$i.log; }
+  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc/pass_$i -- $CMD --cpu-seconds 0 > $out/pmc_$i.log 2>&1 || { echo "pmc pass $i ($set) failed"; tail -5 $out/pmc_$i.log; }
   [ $i = 1 ] && grep '^{' $out/pmc_$i.log | tail -1 > $out/pmc/bench_pass.json
 done
-python3 tools/pmc_roofline.py $out/pmc $kern $out/counters_$kern.json "$CMD (PMC passes: --cpu-seconds 0 --no-profile)" > $out/pmc_roofline.log 2>&1 || tail -5 $out/pmc_roofline.log
+python3 tools/pmc_roofline.py $out/pmc $kern $out/counters_$kern.json "$CMD (PMC passes: --cpu-seconds 0)" > $out/pmc_roofline.log 2>&1 || tail -5 $out/pmc_roofline.log
 rm -rf $out/stats $out/pmc
 cut -c1-400 $out/bench.json; head -4 $out/kernel_stats.csv; cat $out/counters_$kern.json
