@@ -1163,13 +1163,15 @@ int rt_get_counters(rt_ctx* c, RtCounters* out) {
     out->traceLaunches = c->traceLaunchesTotal;
     out->emitterTests = h.emitterTests;
     if (c->phaseStats) {
-        unsigned long long ps[12];
+        unsigned long long ps[15];
         RT_HIP(c, hipMemcpy(ps, (char*)c->counterBuf.p + sizeof(DevCounters), sizeof(ps), hipMemcpyDeviceToHost));
         static const char* nm[4] = {"refill", "setup", "interior", "leaf"};
         for (int k = 0; k < 4; k++)
             fprintf(stderr, "[phase_stats] %-8s rounds %12llu lanes %14llu avg active %.1f  clocks/round %8.0f  share of wave time %.1f %%\n", nm[k], ps[k], ps[4 + k],
                     ps[k] ? (double)ps[4 + k] / ps[k] : 0.0, ps[k] ? (double)ps[8 + k] / ps[k] : 0.0,
                     100.0 * ps[8 + k] / std::max(1.0, (double)(ps[8] + ps[9] + ps[10] + ps[11])));
+        fprintf(stderr, "[phase_stats] lanes sitting out interior rounds: %.1f at a leaf, %.1f in set-up states, %.1f without a ray (of 64, average)\n",
+                ps[2] ? (double)ps[12] / ps[2] : 0.0, ps[2] ? (double)ps[13] / ps[2] : 0.0, ps[2] ? (double)ps[14] / ps[2] : 0.0);
         if (c->waveTimesCount && c->waveTimeBuf.p) {  // the last k_trace_pw launch: when did its waves finish?
             std::vector<unsigned long long> t(c->waveTimesCount * 2);
             RT_HIP(c, hipMemcpy(t.data(), c->waveTimeBuf.p, t.size() * 8, hipMemcpyDeviceToHost));

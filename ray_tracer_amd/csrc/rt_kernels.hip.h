@@ -532,6 +532,7 @@ struct WaveTotals {
     uint32_t totBox = 0, totTri = 0, totRays = 0, totHits = 0;
     uint32_t dbgRounds[4] = {0, 0, 0, 0}, dbgLanes[4] = {0, 0, 0, 0};  // refill, setup, interior, leaf (STATS)
     unsigned long long dbgCycles[4] = {0, 0, 0, 0};                    // shader clocks spent in rounds of each kind (STATS)
+    uint32_t dbgWait[3] = {0, 0, 0};  // STATS: lanes that sat out interior rounds at a leaf / in set-up states / without a ray
 };
 
 // OVF: the BVH is deeper than STACK; entries beyond the LDS part live in a global overflow buffer
@@ -783,7 +784,12 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
 
         if (runI) {
             // ================= interior step: both children of the pair `cur` =================
-            if (STATS) { wt.dbgRounds[2]++; wt.dbgLanes[2] += nI; }
+            if (STATS) {
+                wt.dbgRounds[2]++; wt.dbgLanes[2] += nI;
+                wt.dbgWait[0] += __popcll(__ballot((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX));
+                wt.dbgWait[1] += __popcll(__ballot(cur >= RT_CUR_LEAF_MAX && cur != RT_CUR_IDLE));
+                wt.dbgWait[2] += __popcll(__ballot(cur == RT_CUR_IDLE));
+            }
             if ((int32_t)cur >= 0) {
                 const float4* pr = sc.nodesPk + 2 * (size_t)cur;
                 const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
@@ -863,6 +869,7 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
             atomicAdd(&ta.phaseStats[k], (unsigned long long)wt.dbgRounds[k]);
             atomicAdd(&ta.phaseStats[4 + k], (unsigned long long)wt.dbgLanes[k]);
             atomicAdd(&ta.phaseStats[8 + k], wt.dbgCycles[k]);
+            if (k < 3) atomicAdd(&ta.phaseStats[12 + k], (unsigned long long)wt.dbgWait[k]);
         }
     }
     unsigned long long wb = wave_sum_u64(wt.totBox), wtri = wave_sum_u64(wt.totTri);

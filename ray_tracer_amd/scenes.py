@@ -352,10 +352,14 @@ def sponza(dragons=0, ntris=SPONZA_TRIS, seed=1, flatten=False):
               engine.default_material(albedo=(0, 0, 0), emissionColor=(1, 1, 1), emissionStrength=2.4),
               engine.default_material(reflectance=1.0), engine.default_material(ior=2.0)):
         s.add_material(m)
-    real = _asset("sponza.obj")
+    real = _asset("sponza.obj") or _asset(os.path.join("sponza2", "sponza_tri.obj"))
     if real:
-        s.read_obj(real, engine.placement(scale=0.01, position=(0, 0.5, 0)), 0)
-        label = "sponza.obj"
+        # as the reference places it (src/vk_engine.cpp:726-729: scale 1, no rotation, origin): an identity transform, so its
+        # usemtl groups take the traversal's identity path like the stand-in's. The file's own units then apply: the camera of
+        # sponza_camera() and the Cornell emitter at y = -1.5 are set for the stand-in's atrium (24 x 10 x 9 units) and have to be
+        # moved by the caller for a model in other units (--camera-position / --fov of the CLI)
+        s.read_obj(real, engine.placement(), 0)
+        label = os.path.basename(real)
     else:
         mtl = _asset("sponza.mtl")
         first = s.counts()["materials"]
