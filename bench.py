@@ -1,24 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s of the wavefront path tracer on the BASELINE.json workload.
 
-A "step" is one dispatch of the hot path (rt_render = the reference's
-run_compute + raytrace.comp) over the whole 1920x1080 Sponza frame at --spp
-samples per pixel, with frameCount advancing per step as in the reference's
-progressive mode (src/vk_engine.cpp:1812-1814). With N GPUs the framebuffer is
-tiled by interleaved rows (rank r renders rows r, r+N, ...), the scene is
-replicated, there is no mid-frame traffic, and each step ends with one RCCL
-gather of the fp32 strips to rank 0 (total work fixed => "strong" scaling).
+A "step" is one dispatch of the hot path (rt_render = the reference's run_compute + raytrace.comp) over the whole 1920x1080
+Sponza frame at --spp samples per pixel, with frameCount advancing per step as in the reference's progressive mode
+(src/vk_engine.cpp:1812-1814). With N GPUs the framebuffer is tiled by interleaved rows (rank r renders rows r, r+N, ...),
+the scene is replicated, there is no mid-frame traffic, and the fp32 strips are gathered to rank 0 over RCCL (total work fixed
+=> "strong" scaling). Steps are independent until they are blended, so a rank submits --frames-in-flight of them at once
+(rt_render_frames: their pixels share a launch, the blends follow in frame order — the same bits as one dispatch per step).
 
-value   = reference-semantics rays / s: 1 ray = 1 calculateIntersections call
-          of shaders/raytrace.comp (4 per diffuse segment).
-          `unique_mrays_per_s` beside it counts only the closest-hit queries
-          the GPU actually executed (duplicate NEE probe merged, probes of
-          terminated paths skipped) — the roofline uses only executed work.
-roofline: algorithmic bytes (32 B per box test + 36 B per triangle test +
-          100 B per reported hit, counters summed by the traversal kernel
-          itself) / HIP-event time of the traversal kernel launches.
-cpu_baseline: the scalar oracle (oracle/, a port of the shader) timed on this
-          host's cores on a bounded sample of the same frame.
+value    = reference-semantics rays / s: 1 ray = 1 calculateIntersections call of shaders/raytrace.comp (4 per diffuse
+           segment). `unique_mrays_per_s` beside it counts only the scene queries the GPU actually executed (the
+           duplicate NEE query merged, light queries answered from the emitter list not traced, the camera ray traced once per
+           pixel and dispatch) — the roofline uses only executed work.
+roofline : achieved / frac = algorithmic bytes (32 B per box test + 36 B per triangle test + 100 B per reported hit, counted by
+           the kernel itself) / HIP-event time of the kernel's launches, against 8 TB/s; next to it what the PMC
+           counters of the same binary say (profiles/counters_*.json, stamped with a hash of the kernel sources): traffic and
+           hbm_counter_frac, TA busy, VALU issue, active lanes, L1 look-ups per ray.
+cpu_baseline: the scalar oracle (oracle/, a port of the shader) timed on this host's cores on a bounded sample of the same frame;
+parity_check: those very rows rendered by the GPU and compared bit for bit (the oracle is the checker, never the product).
 """
 import argparse
 import json
@@ -275,6 +274,9 @@ def cpu_baseline(scene, pc, W, H, args):
     """The scalar oracle on this host's cores, on every k-th row of the same frame."""
     from oracle import pyoracle
     threads = pyoracle.effective_cpus()
+    # timed as the shader's own work only: without the oracle's second evaluation of every light query (its check of the
+    # pipeline's shortcut, which the parity tests use); the pixels are the same either way
+    pyoracle.lib().oracle_set_light_queries(0)
     pc.frameCount = 0
     # calibrate on 4 rows spread over the frame, then size the sample for ~cpu_seconds
     probe_rows = 4
@@ -290,7 +292,8 @@ def cpu_baseline(scene, pc, W, H, args):
     return ({"value": c["raysReference"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{n_rows} of {H} rows (every {stride}th) of the same {W}x{H} frame at {args.spp} spp, "
                       f"{c['raysReference']} rays in {dt:.1f} s",
-            "unique_mrays_per_s": c["raysTraced"] / dt / 1e6}, rows, dict(row0=0, rowStride=stride, nRows=n_rows))
+            "what": "scalar C++ restatement of raytrace.comp: every calculateIntersections call of the shader is executed (4 per diffuse segment)"},
+            rows, dict(row0=0, rowStride=stride, nRows=n_rows))
 
 
 if __name__ == "__main__":
