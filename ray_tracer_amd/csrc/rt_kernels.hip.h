@@ -107,7 +107,7 @@ struct PathState {
     __host__ __device__ __forceinline__ float4* auxO() const { return arr(2); }        // origin of the probe rays   | w: max(0, dot(n, lightSample))          (:460)
     __host__ __device__ __forceinline__ float4* auxDL() const { return arr(3); }       // NEE direction              | w: cosineHemispherePDF(n, lightSample)  (:448)
     __host__ __device__ __forceinline__ float4* auxDC() const { return arr(4); }       // cosine-sample direction    | w: cosineHemispherePDF(n, cosineSample) (:454)
-    __host__ __device__ __forceinline__ float4* hit(uint32_t kind) const { return arr(5 + kind); }  // per ray kind: {dst, object bits, triangle bits, -}
+    __host__ __device__ __forceinline__ float4* hit(uint32_t kind) const { return arr(5 + kind); }  // per ray kind. From the ray's creator: {closest sphere hit, its object bits, object mask, tE of a light query or 0}; from the traversal: {dst, object bits, triangle bits, 0}
     __host__ __device__ __forceinline__ float4* att() const { return arr(8); }         // attenuation                | w: bounce index j, bit 31 = NEE results pending
     __host__ __device__ __forceinline__ float4* total() const { return arr(9); }       // totalColor                 | w: samples finished for this pixel
     __host__ __device__ __forceinline__ float4* direct() const { return arr(10); }     // directLight

@@ -773,3 +773,12 @@ def test_render_frames_equals_frame_by_frame(renderer):
                 assert c_all[k] == c_seq[k], k
     finally:
         renderer.set_tuning("frames_per_launch", 0)
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("RT_RANDOM_SEEDS", "6")))))
+def test_random_emitter_scenes(renderer, seed):
+    """Random emissive triangles and spheres among random occluders (tests/util.py): the light queries' skip and early stop
+    against the oracle — pixels, executed-work counters, and the oracle's own check of every answer."""
+    from util import random_emitter_scene
+    s, pc, W, H = random_emitter_scene(seed)
+    _check(*_render_both(renderer, s, pc, W, H))

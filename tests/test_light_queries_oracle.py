@@ -75,24 +75,7 @@ def test_shortcut_is_off_when_it_would_not_be_exact_or_cheap():
 
 @pytest.mark.parametrize("seed", range(6))
 def test_random_emitters(seed):
-    rng = np.random.default_rng(4000 + seed)
-    s = cornell_scene(False)
-    mats = [0, 1, 2, 4, 5]
-    for _ in range(2):
-        mats.append(s.add_material(engine.default_material(albedo=tuple(rng.random(3)), emissionColor=tuple(rng.random(3)),
-                                                            emissionStrength=float(rng.random() * 3 + 0.1))))
-    for k in range(int(rng.integers(2, 6))):
-        n = int(rng.integers(1, 9))
-        tri = rng.uniform(-0.8, 0.8, (n, 3, 3)).astype(np.float32)
-        tri[:, :, 1] -= 0.5
-        tri[:, 1:, :] = tri[:, :1, :] + rng.uniform(-0.35, 0.35, (n, 2, 3)).astype(np.float32)
-        nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
-        nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-9)
-        pl = engine.placement(rotation=tuple(rng.uniform(-40, 40, 3)), scale=tuple(rng.uniform(0.6, 1.2, 3))) if rng.random() < 0.5 else engine.placement()
-        s.add_mesh(f"e{seed}_{k}", tri, np.repeat(nrm[:, None, :], 3, axis=1).astype(np.float32), pl, int(rng.choice(mats)))
-    for i in range(int(rng.integers(0, 5))):
-        s.set_sphere(i, tuple(rng.uniform(-0.7, 0.7, 3)), float(rng.uniform(0.05, 0.3)), int(rng.choice(mats)))
-    W, H = 80, 60
-    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2, bounceLimit=int(rng.integers(2, 9)), environmentOn=bool(seed % 2))
+    from util import random_emitter_scene
+    s, pc, W, H = random_emitter_scene(seed)
     _, c = pyoracle.render(s, pc, W, H)
     assert c["lightQueryMismatch"] == 0
