@@ -891,11 +891,18 @@ struct FullHit {
     rt_vec3 hitPoint, normal;
     uint32_t materialIndex;
     bool frontFace;
-    float bu, bv, bw;   // the triangle test's u, v, w (raytrace.comp:238-240); unset for spheres
 };
 
 // hit.uv (raytrace.comp:249-256) and the albedo texel at (u, 1 - v); the declared texture semantics of include/rt_amd.h
-__device__ __forceinline__ rt_vec3 albedo_texel(const DevScene& sc, uint32_t slot, uint32_t tri, uint32_t obj, float bu, float bv, float bw) {
+// (the triangle test is run again for its u, v, w rather than carried through shade_path in three registers: textured hits are rare)
+__device__ __forceinline__ rt_vec3 albedo_texel(const DevScene& sc, uint32_t slot, uint32_t tri, uint32_t obj, rt_vec3 ro, rt_vec3 rd) {
+    float bu, bv, bw;
+    {
+        const float4 i0 = sc.objInv[3 * obj], i1 = sc.objInv[3 * obj + 1], i2 = sc.objInv[3 * obj + 2];
+        const float4 p0 = sc.triPos[3 * (size_t)tri], p1 = sc.triPos[3 * (size_t)tri + 1], p2 = sc.triPos[3 * (size_t)tri + 2];
+        const TriHit h = tri_intersect(xform_point_rows(i0, i1, i2, ro), xform_dir_rows(i0, i1, i2, rd), f4xyz(p0), f4xyz(p1), f4xyz(p2), __float_as_uint(p0.w) != 0u);
+        bu = h.u; bv = h.v; bw = h.w;
+    }
     const float4 a = sc.triUV[2 * (size_t)tri], b = sc.triUV[2 * (size_t)tri + 1];  // {u0 v0 u1 v1} {u2 v2}
     float u = (bw * a.x + bu * a.z) + bv * b.x, v = (bw * a.y + bu * a.w) + bv * b.y;
     const bool e01 = a.x == a.z && a.y == a.w, e12 = a.z == b.x && a.w == b.y, e20 = b.x == a.x && b.y == a.y;
@@ -933,7 +940,6 @@ __device__ __forceinline__ FullHit reconstruct_hit(const DevScene& sc, rt_vec3 r
     f.hitPoint = xform_point_rows(m0, m1, m2, op);
     f.materialIndex = sc.objMeta[obj].z;
     f.frontFace = h.frontFace;
-    f.bu = h.u; f.bv = h.v; f.bw = h.w;
     return f;
 }
 
@@ -1148,7 +1154,7 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
                 refRays += 3;
                 rt_vec3 albedo = rt_v3(mA.x, mA.y, mA.z);
                 const uint32_t texSlot = __float_as_uint(mI.y);   // albedoIndex; 0xffffffff (-1) = none
-                if (texSlot < sc.texCount && !(obj & RT_HIT_SPHERE)) albedo = rt_mul(albedo, albedo_texel(sc, texSlot, hitTriIdx, obj, hit.bu, hit.bv, hit.bw));
+                if (texSlot < sc.texCount && !(obj & RT_HIT_SPHERE)) albedo = rt_mul(albedo, albedo_texel(sc, texSlot, hitTriIdx, obj, ro, rd));
                 rt_vec3 origin = rt_add(hit.hitPoint, rt_scale(hit.normal, 0.01f));
                 // lightSampleDir (:368-387)
                 float lx = rt_random(&state);
