@@ -52,9 +52,10 @@ def main():
                     help="send a one-rank job through the process group, gather and reductions too (RCCL smoke test on a one-GPU box)")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole frame alone and compares it with the gathered one")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="steps (= progressive frames) a rank submits at once through rt_render_frames; 0 = N on N GPUs (a 1/N tile "
-                         "has too few pixels to fill a GPU, because a pixel's samples are serial; N frames of it do) and 2 on one GPU "
-                         "(the second frame's pixels fill the first one's tail: -2.6 %), 1 = every step its own dispatch and its own gather")
+                    help="most steps (= progressive frames) a rank submits at once through rt_render_frames; 0 = 2 N on N GPUs: a 1/N "
+                         "tile has too few pixels to fill a GPU, because a pixel's samples are serial; N frames of it are one frame's "
+                         "worth of pixels, and a second frame's worth fills the first one's tail (-2.6 % on one GPU). The steps of a "
+                         "run are split into equal groups of at most that many. 1 = every step its own dispatch and its own gather")
     args = ap.parse_args()
 
     import numpy as np
@@ -112,7 +113,7 @@ def main():
     # Steps are progressive frames: independent until they are blended in order. A rank may therefore submit a group of
     # them at once (rt_render_frames: their pixels share a launch, the blends follow in frame order — the same bits as
     # one dispatch per step); the strips are gathered once per group.
-    fif = args.frames_in_flight if args.frames_in_flight > 0 else max(world, 2)
+    fif = args.frames_in_flight if args.frames_in_flight > 0 else 2 * world
 
     def launch(i, n):
         pc.frameCount = i
@@ -144,10 +145,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def groups(count):
+        """`count` steps in the fewest groups of at most `fif`, sized evenly (20 steps, at most 16 at once: 10 + 10, not 16 + 4 —
+        a small last group would leave the GPU half empty, which is what the groups are there to avoid)."""
+        if count <= 0:
+            return []
+        k = (count + fif - 1) // fif
+        return [count // k + (1 if j < count % k else 0) for j in range(k)]
+
     def run(first, count):
         i = first
-        while i < first + count:
-            n = min(fif, first + count - i)
+        for n in groups(count):
             step(i, n)
             i += n
 
@@ -187,7 +195,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} ({label}), {W}x{H}, {args.spp} spp/step, bounceLimit 8, "
-                                   f"rows interleaved over {world} GPU(s)" + f", {fif} steps in flight per rank" + (", one RCCL gather per group" if world > 1 else ""),
+                                   f"rows interleaved over {world} GPU(s)" + f", up to {fif} steps in flight per rank (groups of {'+'.join(map(str, groups(args.steps)))})" + (", one RCCL gather per group" if world > 1 else ""),
                        "scene": args.scene, "assets": label, "width": W, "height": H, "spp_per_step": args.spp, "frames_in_flight": fif,
                        "pipeline": ["multi-kernel (k_trace_pw + k_shade per round)", "fused (k_render_fused)"][r.last_pipeline()]},
             "unique_mrays_per_s": tot["raysTraced"] / dt / 1e6,

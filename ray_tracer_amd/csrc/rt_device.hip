@@ -558,6 +558,13 @@ int rt_update_spheres(rt_ctx* c, const Sphere* s, uint32_t n) {
     c->sc.spheres = (const float4*)c->sphereBuf.p;
     c->sc.sphereMat = (const uint32_t*)c->sphereMatBuf.p;
     c->sc.sphereCount = n;
+    // spheres whose {center, radius} repeat an earlier sphere's bit for bit are not tested by the rays' creators (DevScene::sphereTestMask)
+    c->sc.sphereTestMask = 0;
+    for (uint32_t i = 0; i < std::min(n, 32u); i++) {
+        bool repeat = false;
+        for (uint32_t k = 0; k < i && !repeat; k++) repeat = memcmp(&sp[i], &sp[k], sizeof(float4)) == 0;
+        if (!repeat) c->sc.sphereTestMask |= 1u << i;
+    }
     c->hostSphereMat.assign(sm.begin(), sm.begin() + n);
     return rebuild_emitters(c);
 }
@@ -636,14 +643,20 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
     if ((rc = upload(c, c->objMetaBuf, meta.data(), meta.size() * sizeof(uint4)))) return rc;
     if ((rc = upload(c, c->objBoxBuf, wbox.data(), wbox.size() * sizeof(float4)))) return rc;
     c->sc.objBox = (const float4*)c->objBoxBuf.p;
-    // the objects (of the first 32) a ray's creator tests for the ray's object mask, compact: {lo.xyz, object index} {hi.xyz, -}
+    // the objects a ray's creator tests for the ray's object mask, compact: {lo.xyz, position in the window} {hi.xyz, -}. The mask
+    // has 32 bits; its window starts at the first object that can be ruled out at all, so that a scene like C5 (26 identity
+    // groups, then sixteen placed dragons) has all its placed objects under the mask
     std::vector<float4> maskBox(64, make_float4(0.f, 0.f, 0.f, 0.f));
     c->sc.reachCount = 0;
-    for (uint32_t i = 0; i < std::min(n, 32u); i++)
+    uint32_t maskBase = 0;
+    while (maskBase < n && !(meta[maskBase].w & 4u)) maskBase++;
+    if (maskBase >= n) maskBase = 0;
+    c->sc.maskBase = maskBase;
+    for (uint32_t i = maskBase; i < std::min(n, maskBase + 32u); i++)
         if (meta[i].w & 4u) {
-            const uint32_t k = c->sc.reachCount++;
+            const uint32_t k = c->sc.reachCount++, w = i - maskBase;
             maskBox[2 * k] = wbox[2 * (size_t)i]; maskBox[2 * k + 1] = wbox[2 * (size_t)i + 1];
-            memcpy(&maskBox[2 * k].w, &i, 4);
+            memcpy(&maskBox[2 * k].w, &w, 4);
         }
     // one general-transform object among identity ones (Sponza's emitter) does not pay for either mechanism: measured +3 % and
     // +8..19 % on that scene; from two on they do (Cornell + model: -5..-13 %)
@@ -657,12 +670,13 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
     c->sc.maskBox = (const float4*)c->maskBoxBuf.p;
     // what the reference spends on objects [0, i) when a ray misses them all: two box tests per interior root, the root's
     // triangles per leaf root. A run of skipped objects costs the difference of two entries (trace_wave: fetch_next_meta).
-    std::vector<uint2> skipCost(33, make_uint2(0u, 0u));
-    for (uint32_t i = 0; i < 32u; i++) {
-        skipCost[i + 1] = skipCost[i];
+    std::vector<uint2> skipCost(33, make_uint2(0u, 0u));  // over the mask's window
+    for (uint32_t w = 0; w < 32u; w++) {
+        const uint32_t i = maskBase + w;
+        skipCost[w + 1] = skipCost[w];
         if (i < n) {
-            if (meta[i].y == 0u) skipCost[i + 1].x += 2u;
-            else skipCost[i + 1].y += meta[i].y;
+            if (meta[i].y == 0u) skipCost[w + 1].x += 2u;
+            else skipCost[w + 1].y += meta[i].y;
         }
     }
     if ((rc = upload(c, c->objSkipBuf, skipCost.data(), skipCost.size() * sizeof(uint2)))) return rc;

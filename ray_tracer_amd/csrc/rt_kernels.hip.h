@@ -67,9 +67,15 @@ struct DevScene {
     const float4* spheres;
     const uint32_t* sphereMat;
     uint32_t sphereCount, objectCount, materialCount, nodeCount, triCount;
+    uint32_t sphereTestMask;  // spheres sphere_seed has to test: all but those whose {center, radius} repeat an earlier sphere's bit for
+                              // bit (the reference always uploads MAX_SPHERES = 10, src/vk_engine.cpp:682-686, zeroed when unused).
+                              // A repeat computes the earlier sphere's very result and can never win the loop's strict `dst < best`
+                              // (raytrace.comp:282-287), so leaving it out changes nothing
     const float4* maskBox;   // reachCount x 2 float4: the objects a ray's creator tests for the ray's object mask (reach_mask_from)
-    const uint2* objSkipCost; // 33 entries: {box tests, triangle tests} the reference spends on objects [0, i) when a ray misses them all
+    const uint2* objSkipCost; // 33 entries: {box tests, triangle tests} the reference spends on objects [maskBase, maskBase + i) when a ray misses them all
     uint32_t reachCount;     // entries of maskBox
+    uint32_t maskBase;       // a ray's object mask covers objects [maskBase, maskBase + 32): the window starts at the first object that can be
+                             // ruled out at all (C5: 26 identity-transform groups, then sixteen placed dragons — all sixteen inside the window)
     // Light queries (the NEE ray and the cosine probe of a diffuse bounce, raytrace.comp:443-453) only ask "is the closest hit
     // emissive, and how far is it". emitTris lists every triangle of every object whose material is emissive ({object,
     // triangle}, sorted by object), emitSphereMask the emissive spheres; the creator of such a ray tests them all and knows the
@@ -224,12 +230,12 @@ __device__ __forceinline__ bool ray_is_plain(rt_vec3 wo, rt_vec3 wd) {
 }
 
 // What the creator of a ray hands to the traversal (hit record of the ray's kind): the closest sphere hit (the shader's
-// sphere loop, raytrace.comp:282-287) and, in .z, the objects among the first 32 the ray has to enter at all. Bit i is
-// cleared when object i has an identity transform and an interior root and the ray misses the root's box (objBox holds it,
+// sphere loop, raytrace.comp:282-287) and, in .z, the objects among the 32 of the mask's window (DevScene::maskBase) the ray
+// has to enter at all. Bit i is cleared when object maskBase + i has an identity transform and an interior root and the ray misses the root's box (objBox holds it,
 // exactly): both of the root's children are then missed as well, the reference does its two box tests on them and moves
 // on, and so does the traversal — by adding 2 to the count (trace_wave: fetch_next_meta). On the Sponza stand-in a ray
 // misses 16 of the 26 material groups' boxes on average. Same slab arithmetic as the traversal's (1/dir, box_intersect).
-// boxes: DevScene::maskBox, wherever the caller keeps it (k_render_fused: in LDS): n objects {lo.xyz, object index} {hi.xyz, -}
+// boxes: DevScene::maskBox, wherever the caller keeps it (k_render_fused: in LDS): n objects {lo.xyz, object index - maskBase} {hi.xyz, -}
 __device__ __forceinline__ bool origin_within(rt_vec3 o, float limit) {
     return rt_max(rt_max(rt_abs(o.x), rt_abs(o.y)), rt_abs(o.z)) <= limit;
 }
@@ -252,7 +258,13 @@ __device__ __forceinline__ uint32_t reach_mask(const DevScene& sc, rt_vec3 ro, r
 __device__ __forceinline__ float4 sphere_seed(const DevScene& sc, rt_vec3 ro, rt_vec3 rd, bool withMask = true) {
     float best = RT_MISS_DST;
     uint32_t obj = RT_HIT_NONE;
-    for (uint32_t i = 0; i < sc.sphereCount; i++) {
+    for (uint32_t m = sc.sphereTestMask; m; m &= m - 1u) {  // ascending, as the shader's loop; repeats of an earlier sphere left out
+        const uint32_t i = (uint32_t)__ffs((int)m) - 1u;
+        if (i >= sc.sphereCount) break;
+        SphereHit h = sphere_intersect(sc.spheres[i], ro, rd);
+        if (h.didHit && h.dst < best) { best = h.dst; obj = RT_HIT_SPHERE | i; }
+    }
+    for (uint32_t i = 32; i < sc.sphereCount; i++) {  // beyond the mask (the reference has ten spheres)
         SphereHit h = sphere_intersect(sc.spheres[i], ro, rd);
         if (h.didHit && h.dst < best) { best = h.dst; obj = RT_HIT_SPHERE | i; }
     }
@@ -572,18 +584,19 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
 
     uint32_t thr = ta.fastLanes;
 
-    uint32_t reach = 0xffffffffu;  // objects (of the first 32) the ray has to enter, from its creator (sphere_seed)
+    uint32_t reach = 0xffffffffu;  // objects (of the mask's window) the ray has to enter, from its creator (sphere_seed)
 
     // Called right after `obj` moved past the object that is being entered: obj - 1 is the object under traversal. The
     // objects after it that the ray's mask rules out are jumped over here (two box tests each, nothing else), and how many
     // were is kept in nxFlags[15:8], so that the object under traversal is still obj - 1 - skipped (cur_object()).
     auto fetch_next_meta = [&]() {
         uint32_t skip = 0;
-        if (CULL && obj < 32u) {
-            const uint32_t m = reach >> obj;
-            skip = m ? (uint32_t)__ffs((int)m) - 1u : 32u - obj;
+        if (CULL && obj - sc.maskBase < 32u) {
+            const uint32_t w = obj - sc.maskBase;  // position in the mask's window
+            const uint32_t m = reach >> w;
+            skip = m ? (uint32_t)__ffs((int)m) - 1u : 32u - w;
             if (skip) {
-                const uint2 c0 = sc.objSkipCost[obj], c1 = sc.objSkipCost[obj + skip];
+                const uint2 c0 = sc.objSkipCost[w], c1 = sc.objSkipCost[w + skip];
                 if (PIX) { rayBox += c1.x - c0.x; rayTri += c1.y - c0.y; } else { wt.totBox += c1.x - c0.x; wt.totTri += c1.y - c0.y; }
             }
             obj += skip;
@@ -702,7 +715,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                             // (fetch_next_meta); the query ends before the reference's loop would have reached them
                             const uint32_t ahead = nxFlags >> 8;
                             if (ahead) {
-                                const uint2 c0 = sc.objSkipCost[obj - ahead], c1 = sc.objSkipCost[obj];
+                                const uint2 c0 = sc.objSkipCost[obj - sc.maskBase - ahead], c1 = sc.objSkipCost[obj - sc.maskBase];
                                 if (PIX) { rayBox -= c1.x - c0.x; rayTri -= c1.y - c0.y; } else { wt.totBox -= c1.x - c0.x; wt.totTri -= c1.y - c0.y; }
                             }
                         }
@@ -1415,15 +1428,20 @@ struct FusedKernArgs {  // the whole kernel-argument segment, so that it can be 
     FusedArgs fa;
 };
 
+// PIX (the heat maps' per-ray counters, two more registers through the traversal loop) is built for four blocks per CU:
+// at five the instantiation <24, false, true, true> spilled 110 VGPRs / 60 SGPRs and its per-ray counts came out wrong on a
+// pixel's second and later samples (klein bottle + Cornell, debug 2: 28 box tests short of 1.7 M) while its rays, hits and
+// radiance stayed bit-identical — the same source built for four blocks (no spills to speak of) counts right, as do all the
+// other instantiations; profiles/README.md, "r02 a miscounting heat-map instantiation". Heat maps are a debug view; speed is not the point there.
 template <int STACK, bool OVF, bool PIX, bool CULL>
-__global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) {
+__global__ __launch_bounds__(RT_BLOCK, PIX ? 4 : 5) void k_render_fused(FusedKernArgs ka) {
     const DevScene& sc = ka.sc;
     const PathState& ps = ka.ps;
     const FrameParams& fp = ka.fp;
     const FusedArgs& fa = ka.fa;
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];
     __shared__ uint32_t s_list[RT_BLOCK / RT_WAVE][3 * RT_WAVE];
-    __shared__ float4 s_box[64];  // objBox of the first 32 objects: the rays' object masks are computed from here (reach_mask_from)
+    __shared__ float4 s_box[64];  // DevScene::maskBox (the objects of the mask's window that can be ruled out): the rays' object masks are computed from here (reach_mask_from)
     const uint32_t nBox = CULL ? sc.reachCount : 0u;
     if (CULL && threadIdx.x < 2u * nBox) s_box[threadIdx.x] = sc.maskBox[threadIdx.x];
     __syncthreads();

@@ -51,14 +51,14 @@ def test_one_rank_job_through_rccl_stitches_the_single_process_frame():
 def test_four_rank_rehearsal_on_one_gpu_stitches_the_single_process_frame():
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed on the one GPU
     of the box: four ranks over gloo (RCCL cannot put two ranks on one device; the box admits at most six processes with the
-    GPU open, and the test runner is one of them), each renders rows r, r+4, ... of every step, four steps in flight per rank
-    (rt_render_frames), one gather per group. 181 rows do not divide by four and seven steps do not divide by the group size. --check: rank 0 re-renders all
+    GPU open, and the test runner is one of them), each renders rows r, r+4, ... of every step, up to four steps in flight per rank
+    (rt_render_frames: groups of 4 + 3), one gather per group. 181 rows do not divide by four and seven steps do not divide by the group size. --check: rank 0 re-renders all
     steps alone, one dispatch per step, and the stitched frame must equal it bit for bit."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
                         "--master-port", "29561", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "1",
                         "--spp", "2", "--scene", "bunny", "--width", "320", "--height", "181", "--cpu-seconds", "0",
-                        "--backend", "gloo", "--check"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                        "--backend", "gloo", "--frames-in-flight", "4", "--check"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["check_tiled_equals_single"] is True

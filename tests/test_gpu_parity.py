@@ -405,6 +405,32 @@ def test_instances_nonuniform_transforms_emissive_mesh_and_ten_spheres(renderer)
     _check(*_render_both(renderer, s, pc, W, H))
 
 
+def test_repeated_spheres_of_different_materials(renderer):
+    """Spheres that repeat an earlier sphere's centre and radius bit for bit are left out by the rays' creators
+    (DevScene::sphereTestMask): the shader's loop would compute the earlier sphere's result again and never prefer it
+    (strict `<`, raytrace.comp:282-287). Here the repeats carry other materials (emissive, mirror, dielectric) than their
+    originals, sit before and after distinct spheres, one pair is emissive twice, and a dispatch with fewer spheres than
+    were uploaded cuts a pair in two; then a sphere is edited in place so that a repeat becomes an original."""
+    s = cornell_scene(False)
+    glow = s.add_material(engine.default_material(albedo=(0.2, 0.2, 0.9), emissionColor=(0.2, 0.4, 1.0), emissionStrength=2.0))
+    a, b, c = ((-0.45, 0.35, 0.1), 0.3), ((0.4, 0.2, -0.2), 0.35), ((0.0, -0.55, 0.3), 0.2)
+    z = ((0.0, 0.0, 0.0), 0.0)  # the reference's unused sphere slots
+    layout = [(a, 0), (b, 4), (a, glow), (c, glow), (b, 5), (c, glow), (a, 4), (z, 0), (z, 3), (b, 0)]
+    for i, ((pos, rad), m) in enumerate(layout):
+        s.set_sphere(i, pos, rad, m)
+    W, H = 96, 72
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3, bounceLimit=6)
+    _check(*_render_both(renderer, s, pc, W, H))
+    pc5 = engine.push_constants(W, H, singleRender=1, sampleLimit=2, bounceLimit=6, sphereCount=5)
+    _check(*_render_both(renderer, s, pc5, W, H))
+    s.set_sphere(0, (-0.5, 0.3, 0.0), 0.25, 1)   # spheres 2 and 6 repeated sphere 0: now sphere 2 is the original of the two
+    renderer.update_spheres(s)
+    renderer.reset_counters()
+    img = renderer.render(pc, W, H)
+    ref, rc = pyoracle.render(s, pc, W, H)
+    _check(img, renderer.counters(), ref, rc)
+
+
 def test_camera_inside_a_mesh_and_grazing_rays(renderer):
     """The camera sits inside the klein bottle (back faces first, frontFace = false paths of the dielectric) and looks along
     a wall (grazing primary rays); a wide field of view sends rays past every edge of the box."""
@@ -500,8 +526,8 @@ def test_random_scenes(renderer, seed):
 def test_more_objects_than_the_object_mask_has_bits(renderer):
     """Forty-five objects: the Cornell box's nine, then thirty-six small meshes alternating between rotated / scaled
     placements (general transforms: entered only when the ray can reach their padded box), identity placements and
-    two-triangle cards whose BVH root is a leaf. The rays' object masks cover the first 32 objects only; the objects
-    beyond them, and the boundary itself, must be walked, counted and credited exactly as the reference's linear loop does."""
+    two-triangle cards whose BVH root is a leaf. The rays' object masks cover 32 objects only (from the first placed one); the
+    objects beyond them, and the boundary itself, must be walked, counted and credited exactly as the reference's linear loop does."""
     s = engine.Scene()
     s.prepare_storage_buffers()
     glow = s.add_material(engine.default_material(albedo=(0.9, 0.9, 0.3), emissionColor=(1.0, 0.9, 0.4), emissionStrength=2.0))
@@ -521,6 +547,45 @@ def test_more_objects_than_the_object_mask_has_bits(renderer):
     assert s.counts()["objects"] == 45
     W, H = 128, 96
     pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3, bounceLimit=6)
+    _check(*_render_both(renderer, s, pc, W, H))
+
+
+@pytest.mark.parametrize("n_identity,n_placed", [(34, 20), (3, 40), (31, 2)])
+def test_object_mask_window_starts_at_the_first_placed_object(renderer, n_identity, n_placed):
+    """C5's shape: identity-transform groups first, placed (general-transform) objects after them. The 32 bits of a ray's
+    object mask start at the first placed object (DevScene::maskBase), so 34 groups + 20 placed objects are all under the
+    mask although they are objects 34..53; with 40 placed objects the window ends inside them; with 31 + 2 it straddles
+    object 32. Leaf-root cards among the placed objects, an emissive one, a light query ending inside a skipped run."""
+    import os
+    s = engine.Scene()            # no Cornell box (its placed walls would come first): materials and spheres as scenes.sponza() sets them
+    for i in range(10):
+        s.set_sphere(i, (0, 0, 0), 0.0, 0)
+    for m in (engine.default_material(), engine.default_material(albedo=(1, 0, 0)), engine.default_material(albedo=(0, 1, 0)),
+              engine.default_material(albedo=(0, 0, 0), emissionColor=(1, 1, 1), emissionStrength=2.4),
+              engine.default_material(reflectance=1.0), engine.default_material(ior=2.0)):
+        s.add_material(m)
+    glow = s.add_material(engine.default_material(albedo=(0.9, 0.9, 0.3), emissionColor=(1.0, 0.9, 0.4), emissionStrength=2.0))
+    mats = [0, 1, 2, 4, 5, glow]
+    card = np.array([[[-0.06, 0, -0.06], [0.06, 0, -0.06], [0.06, 0, 0.06]], [[-0.06, 0, -0.06], [0.06, 0, 0.06], [-0.06, 0, 0.06]]], np.float32)
+    ncard = np.zeros_like(card); ncard[..., 1] = -1
+    fpos, fnrm = scenes.grid_patch((-1.0, 1.0, -1.0), (2.0, 0, 0), (0, 0, 2.0), 6, 6)
+    s.add_mesh("floor", fpos, fnrm, engine.placement(), 0)
+    first = s.counts()["objects"]
+    for k in range(n_identity):
+        where = (-0.8 + 0.27 * (k % 7), 0.9 - 0.12 * (k // 7), -0.8 + 0.2 * (k % 5))
+        pos, nrm = scenes.blob(48 + 4 * k, seed=70 + k, radius=0.06, center=where)
+        s.add_mesh(f"i{k}", pos, nrm, engine.placement(), mats[k % 5])
+    for k in range(n_placed):
+        where = (-0.75 + 0.3 * (k % 6), -0.8 + 0.22 * (k // 6), -0.6 + 0.3 * (k % 4))
+        if k % 4 == 3:
+            s.add_mesh(f"c{k}", card, ncard, engine.placement(position=where, rotation=(35 * k, 0, 20 * k)), mats[k % 6])
+        else:
+            pos, nrm = scenes.blob(80 + 6 * k, seed=90 + k, radius=1.0)
+            s.add_mesh(f"g{k}", pos, nrm, engine.placement(position=where, scale=(0.08, 0.1, 0.07), rotation=(12 * k, 31 * k, 7 * k)), mats[k % 6])
+    s.read_obj(os.path.join(engine.ASSET_DIR, "light2.obj"), engine.placement(position=(0, -1.5, 0), frontOnly=True), 3)
+    assert s.counts()["objects"] == first + n_identity + n_placed + 1
+    W, H = 112, 84
+    pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3, bounceLimit=6, environmentOn=True)
     _check(*_render_both(renderer, s, pc, W, H))
 
 
