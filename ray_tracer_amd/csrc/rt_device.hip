@@ -43,7 +43,7 @@ struct rt_ctx {
     DevScene sc{};
     std::vector<DevBuf> sceneBufs;
     DevBuf texelBuf, texInfoBuf, triUVBuf;
-    DevBuf matBuf, sphereBuf, sphereMatBuf, objInvBuf, objFwdBuf, objMetaBuf, objBoxBuf, objSkipBuf, maskBoxBuf, emitBuf;
+    DevBuf matBuf, sphereBuf, sphereMatBuf, objInvBuf, objFwdBuf, objMetaBuf, objBoxBuf, objSkipBuf, maskBoxBuf, emitBuf, emitPreBuf;
     // host copies of what the emitter list is derived from (rebuild_emitters)
     std::vector<RayMaterial> hostMats;
     std::vector<uint32_t> hostSphereMat, hostObjMat, hostObjRoot;
@@ -403,7 +403,7 @@ int harvest_events(rt_ctx* c) {
     return 0;
 }
 
-// The emitter list of the light queries (rt_kernels.hip.h: emitter_min_t): every triangle of every object whose material is
+// The emitter list of the light queries (rt_kernels.hip.h: emitter_min_t2): every triangle of every object whose material is
 // emissive, and the emissive spheres. "Emissive" is what lightSamplePDF asks (raytrace.comp:392): emissionStrength != 0.
 // The shortcut is only taken when it is cheap (at most RT_EMIT_MAX_TRIS triangles) and exact: the NEE term of a query that
 // is answered "not emissive" is emission * 0, which is 0 only while every material's emissionColor * emissionStrength is finite.
@@ -434,6 +434,16 @@ int rebuild_emitters(rt_ctx* c) {
         if (rc) return rc;
     }
     c->sc.emitTris = (const uint2*)c->emitBuf.p;
+    {   // the ray-independent part of every listed triangle's test, computed on the device with the traversal's own operations
+        int rc = dev_alloc(c, c->emitPreBuf, std::max<size_t>(list.size(), 1) * 4 * sizeof(float4));
+        if (rc) return rc;
+        if (!list.empty()) {
+            hipLaunchKernelGGL(k_emit_precompute, dim3(((uint32_t)list.size() + 63u) / 64u), dim3(64), 0, c->stream, c->sc.triPos, c->sc.emitTris, (uint32_t)list.size(), (float4*)c->emitPreBuf.p);
+            RT_HIP(c, hipGetLastError());
+            RT_HIP(c, hipStreamSynchronize(c->stream));  // set-up time; the renders may go to another stream later (rt_set_stream)
+        }
+        c->sc.emitPre = (const float4*)c->emitPreBuf.p;
+    }
     c->sc.emitCount = (uint32_t)list.size();
     c->sc.emitSphereMask = mask;
     c->sc.emitMode = 1;
@@ -483,7 +493,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->sceneBufs) dev_free(b);
-    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->emitBuf, &c->texelBuf, &c->texInfoBuf, &c->triUVBuf, &c->stateBuf,
+    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->emitBuf, &c->emitPreBuf, &c->texelBuf, &c->texInfoBuf, &c->triUVBuf, &c->stateBuf,
                       &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf, &c->waveTimeBuf, &c->probeBuf})
         dev_free(*b);
     (void)rt_comm_destroy(c);

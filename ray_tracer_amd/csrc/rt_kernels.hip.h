@@ -79,9 +79,11 @@ struct DevScene {
     // Light queries (the NEE ray and the cosine probe of a diffuse bounce, raytrace.comp:443-453) only ask "is the closest hit
     // emissive, and how far is it". emitTris lists every triangle of every object whose material is emissive ({object,
     // triangle}, sorted by object), emitSphereMask the emissive spheres; the creator of such a ray tests them all and knows the
-    // nearest emissive primitive's distance tE before any traversal (emitter_min_t). emitMode 0: too many emissive triangles
+    // nearest emissive primitive's distance tE before any traversal (emitter_min_t2). emitMode 0: too many emissive triangles
     // (or non-finite emission values): every light query is traversed in full, as round 1 did.
     const uint2* emitTris;
+    const float4* emitPre;   // per listed triangle {v0, frontOnly} {v1 - v0} {v2 - v0} {cross(v1 - v0, v2 - v0)}: the part of tri_intersect that
+                             // does not depend on the ray, computed once by k_emit_precompute with tri_intersect's own operations
     uint32_t emitCount, emitSphereMask, emitMode;
     // Textures: texels of all slots back to back (R8G8B8A8_SRGB, one uint32 per texel), texInfo[slot] =
     // {first texel, width, height, -}, triUV = 2 x float4 per triangle {u0 v0 u1 v1} {u2 v2 - -} (cold: read per shaded hit of a
@@ -321,42 +323,76 @@ __device__ __forceinline__ void box_intersect_pair(float4 q0, float4 q1, float4 
     d2 = (fR >= nR && fR > 0.f) ? (nR > 0.f ? nR : 0.f) : RT_MISS_DST;
 }
 
-// Distance of the nearest emissive primitive the ray (ro, rd) hits at all, RT_MISS_DST if it hits none: the emissive spheres
-// and every listed triangle, each tested with the operations the traversal would use (sphere_intersect; the object-space
-// ray of reconstruct_hit and tri_intersect), no bounding boxes involved. Whatever calculateIntersections finds for this ray,
-// an emissive closest hit has exactly one of the distances minimised here, so:
+// Distance of the nearest emissive primitive a ray hits at all, RT_MISS_DST if it hits none, for the two light queries of a
+// diffuse bounce at once (same origin: NEE direction rdA, cosine-sample direction rdB): the emissive spheres and every listed
+// triangle, each tested with the operations the traversal would use (sphere_intersect; the object-space ray of
+// reconstruct_hit and tri_intersect — whose ray-independent part, the edges and their cross product, comes from
+// DevScene::emitPre, and whose origin-dependent part, ro - v0 and its dot with the normal, is shared by the two rays), no
+// bounding boxes involved. Whatever calculateIntersections finds for such a ray, an emissive closest hit has exactly one of
+// the distances minimised here, so:
 //   * tE == RT_MISS_DST: the closest hit cannot be emissive -> lightSamplePDF is 0 and the NEE term is 0 (raytrace.comp:
 //     389-403,443-460) whatever the ray hits; the ray is not traced at all;
 //   * a hit nearer than tE (a sphere, found by the creator, or a triangle, found by the traversal) is not emissive and
 //     the closest hit is at least as near: same conclusion, the traversal stops there (trace_wave, leaf step).
 // Both are statements about computed values only (the minimum of the very numbers the traversal compares), not about
 // geometry, so they hold bit for bit.
-__device__ __forceinline__ float emitter_min_t(const DevScene& sc, rt_vec3 ro, rt_vec3 rd, uint32_t& tested) {
-    float tE = RT_MISS_DST;
+__device__ __forceinline__ void emitter_tri_test(rt_vec3 rov0, float rn, rt_vec3 rd, rt_vec3 e1, rt_vec3 e2, rt_vec3 n, bool frontOnly, float& tE) {
+    // tri_intersect (raytrace.comp:227-247) from `q` on; rov0 = ro - v0, rn = dot(rov0, n), e1 = v1 - v0, e2 = v2 - v0, n = cross(e1, e2)
+    const rt_vec3 q = rt_cross(rov0, rd);
+    const float d0 = -rt_dot(rd, n);
+    const float d = 1.f / d0;
+    const float dst = rn * d;
+    const float u = rt_dot(e2, q) * d;
+    const float v = -rt_dot(e1, q) * d;
+    const float w = 1.f - u - v;
+    const bool frontFace = d0 >= 0.00000001f;
+    const bool didHit = dst >= 0.f && u >= 0.f && v >= 0.f && w >= 0.f && !(!frontFace && frontOnly);
+    if (didHit && dst < tE) tE = dst;
+}
+__device__ __forceinline__ void emitter_min_t2(const DevScene& sc, rt_vec3 ro, rt_vec3 rdA, rt_vec3 rdB, float& tA, float& tB, uint32_t& tested) {
+    tA = RT_MISS_DST; tB = RT_MISS_DST;
     for (uint32_t m = sc.emitSphereMask; m; m &= m - 1u) {
         const uint32_t i = (uint32_t)__ffs((int)m) - 1u;
         if (i >= sc.sphereCount) break;
-        const SphereHit h = sphere_intersect(sc.spheres[i], ro, rd);
-        if (h.didHit && h.dst < tE) tE = h.dst;
-        tested++;
+        const float4 s = sc.spheres[i];
+        const SphereHit hA = sphere_intersect(s, ro, rdA), hB = sphere_intersect(s, ro, rdB);
+        if (hA.didHit && hA.dst < tA) tA = hA.dst;
+        if (hB.didHit && hB.dst < tB) tB = hB.dst;
+        tested += 2u;
     }
     uint32_t curObj = 0xffffffffu;
-    rt_vec3 tro = ro, trd = rd;
+    rt_vec3 tro = ro, trdA = rdA, trdB = rdB;
     for (uint32_t k = 0; k < sc.emitCount; k++) {
-        const uint2 e = sc.emitTris[k];
-        if (e.x >= sc.objectCount) break;  // a dispatch with fewer objects than were uploaded (sorted by object)
-        if (e.x != curObj) {
-            curObj = e.x;
+        const uint32_t o = sc.emitTris[k].x;
+        if (o >= sc.objectCount) break;  // a dispatch with fewer objects than were uploaded (sorted by object)
+        if (o != curObj) {
+            curObj = o;
             const float4 i0 = sc.objInv[3 * curObj], i1 = sc.objInv[3 * curObj + 1], i2 = sc.objInv[3 * curObj + 2];
-            trd = xform_dir_rows(i0, i1, i2, rd);
+            trdA = xform_dir_rows(i0, i1, i2, rdA);
+            trdB = xform_dir_rows(i0, i1, i2, rdB);
             tro = xform_point_rows(i0, i1, i2, ro);
         }
-        const float4 a = sc.triPos[3 * (size_t)e.y], b = sc.triPos[3 * (size_t)e.y + 1], c = sc.triPos[3 * (size_t)e.y + 2];
-        const TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
-        if (h.didHit && h.dst < tE) tE = h.dst;
-        tested++;
+        const float4 p0 = sc.emitPre[4 * k], p1 = sc.emitPre[4 * k + 1], p2 = sc.emitPre[4 * k + 2], p3 = sc.emitPre[4 * k + 3];
+        const rt_vec3 rov0 = rt_sub(tro, f4xyz(p0)), n = f4xyz(p3);
+        const float rn = rt_dot(rov0, n);
+        const bool frontOnly = __float_as_uint(p0.w) != 0u;
+        emitter_tri_test(rov0, rn, trdA, f4xyz(p1), f4xyz(p2), n, frontOnly, tA);
+        emitter_tri_test(rov0, rn, trdB, f4xyz(p1), f4xyz(p2), n, frontOnly, tB);
+        tested += 2u;
     }
-    return tE;
+}
+
+// DevScene::emitPre from the listed triangles' positions: tri_intersect's first lines (raytrace.comp:228-231), same operations
+__global__ void k_emit_precompute(const float4* __restrict__ triPos, const uint2* __restrict__ emitTris, uint32_t n, float4* __restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const size_t t = emitTris[k].y;
+    const float4 a = triPos[3 * t], b = triPos[3 * t + 1], c = triPos[3 * t + 2];
+    const rt_vec3 v0 = f4xyz(a), e1 = rt_sub(f4xyz(b), v0), e2 = rt_sub(f4xyz(c), v0), nn = rt_cross(e1, e2);
+    out[4 * k] = a;
+    out[4 * k + 1] = mk4(e1, 0.f);
+    out[4 * k + 2] = mk4(e2, 0.f);
+    out[4 * k + 3] = mk4(nn, 0.f);
 }
 
 // ---------------------------------------------------------------- leaf references
@@ -700,7 +736,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                             if (h.didHit && h.dst < best) { best = h.dst; bestObj = cur_object(); bestTri = j; closer = true; }
                         }
                     }
-                    // Light queries carry tE, the distance of the nearest emissive primitive they hit at all (emitter_min_t; 0 for
+                    // Light queries carry tE, the distance of the nearest emissive primitive they hit at all (emitter_min_t2; 0 for
                     // every other ray). A hit nearer than tE is not emissive and the closest hit is no farther: the query's answer
                     // is "not emissive" whatever else the ray meets, so it ends here and reports no hit, which is what shade_path
                     // reads as "not emissive". tE is re-read from the ray's hit record on the rare step that finds a hit rather
@@ -1075,9 +1111,9 @@ struct ShadeArgs {
 // One path, one segment: trace()'s loop body (raytrace.comp:495-534) with diffuseBRDF split around the
 // probe rays, plus main()'s sample loop (:571-573). Reads the hit records of the path's rays, writes
 // its next rays. Outputs: alive (the path, or the pixel's next sample, goes on), auxMask (bit 0: the NEE ray, bit 1: the cosine probe
-// of this diffuse bounce have to be traced — a light query that emitter_min_t answers is not; bit 2: the main ray needs no
+// of this diffuse bounce have to be traced — a light query that emitter_min_t2 answers is not; bit 2: the main ray needs no
 // traversal, its hit record is already there: the kept camera hit), refRays (the shader's
-// calculateIntersections calls for this segment), nPaths (1 if a sample finished), emitTests (primitives emitter_min_t tested).
+// calculateIntersections calls for this segment), nPaths (1 if a sample finished), emitTests (primitives emitter_min_t2 tested).
 __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& ps, const FrameParams& fp, uint32_t slot, bool& alive,
                                            uint32_t& auxMask, uint32_t& refRays, uint32_t& nPaths, uint32_t& emitTests, bool withMask = true) {
     bool wantAux = false;  // a diffuse bounce whose MIS the next segment finishes (raytrace.comp:443-460)
@@ -1264,7 +1300,8 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
                 // tE the nearest emissive primitive on the ray: none at all, or a sphere nearer than it, answers "not
                 // emissive" here and now (the record of a ray that hit nothing); otherwise the traversal carries tE in the
                 // record's w and stops at the first hit nearer than it.
-                const float tL = emitter_min_t(sc, auxOrigin, auxL, emitTests), tC = emitter_min_t(sc, auxOrigin, auxC, emitTests);
+                float tL, tC;
+                emitter_min_t2(sc, auxOrigin, auxL, auxC, tL, tC, emitTests);
                 if (!(tL < RT_MISS_DST) || sL.x < tL) { sL.x = RT_MISS_DST; sL.y = __uint_as_float(RT_HIT_NONE); auxMask &= ~1u; }
                 else sL.w = tL;
                 if (!(tC < RT_MISS_DST) || sC.x < tC) { sC.x = RT_MISS_DST; sC.y = __uint_as_float(RT_HIT_NONE); auxMask &= ~2u; }

@@ -12,10 +12,10 @@ from ray_tracer_amd import engine, scenes  # noqa: E402
 quick = "--quick" in sys.argv
 CONFIGS = [  # name, scene, width, height, spp, spp per dispatch
     ("C1 Cornell + 3 spheres", "cornell", 512, 512, 4, 4),
-    ("C2 Cornell + bunny", "bunny", 1920, 1080, 64, 64),
-    ("C3 Cornell + dragon (mirror)", "dragon", 1920, 1080, 256, 64),
-    ("C4 Sponza", "sponza", 1920, 1080, 1024, 64),
-    ("C5 Sponza + 16 dragons, 4K (128 of 4096 spp)", "sponza_dragons", 3840, 2160, 128, 16),
+    ("C2 Cornell + bunny", "bunny", 1920, 1080, 64, 8),          # 8 spp per dispatch: bench.py's step (the reference's default is 1 per frame,
+    ("C3 Cornell + dragon (mirror)", "dragon", 1920, 1080, 256, 8),   # src/vk_engine.h:164, accumulated progressively up to sampleLimit)
+    ("C4 Sponza", "sponza", 1920, 1080, 1024, 8),
+    ("C5 Sponza + 16 dragons, 4K (128 of 4096 spp)", "sponza_dragons", 3840, 2160, 128, 8),
 ]
 r = engine.Renderer(0)
 print("| config | GPUs (rows of rank 0) | spp | time | Mrays/s (reference accounting) | executed Mrays/s | spp/s | algorithmic GB/s | of 8 TB/s | pipeline |")
@@ -36,8 +36,10 @@ for name, key, W, H, spp, per in CONFIGS:
         r.sync()
         t = time.perf_counter()
         i, n = 0, spp // per
-        while i < n:   # one of N GPUs keeps N dispatches (progressive frames) in flight: rt_render_frames
-            k = min(world, n - i)
+        fif = 2 * world                      # as bench.py: at most 2 N dispatches (progressive frames) in flight on one of N GPUs
+        ng = (n + fif - 1) // fif            # (rt_render_frames), in even groups
+        sizes = [n // ng + (1 if j < n % ng else 0) for j in range(ng)]
+        for k in sizes:
             pc.frameCount = i
             if k == 1:
                 r.render(pc, W, H, row0=0, rowStride=world, sync=False)
