@@ -173,7 +173,7 @@ int ensure_state(rt_ctx* c, uint32_t nPixels) {
     if (c->capacity >= nPixels && c->stateBuf.p) return 0;
     const size_t stride4 = (((size_t)nPixels * 16) + 255) & ~(size_t)255;  // bytes per float4 array
     const size_t stride1 = (((size_t)nPixels * 4) + 255) & ~(size_t)255;
-    const int nF4 = 14, nU1 = 2;
+    const int nF4 = 15, nU1 = 2;
     int rc = dev_alloc(c, c->stateBuf, stride4 * nF4 + stride1 * nU1);
     if (rc) return rc;
     PathState& ps = c->ps;

@@ -122,8 +122,9 @@ struct PathState {
     __host__ __device__ __forceinline__ float4* pendAlbedo() const { return arr(11); } // albedo of the previous diffuse hit
     __host__ __device__ __forceinline__ float4* accum() const { return arr(12); }      // sum of trace() over the pixel's samples (:572)
     __host__ __device__ __forceinline__ float4* camHit() const { return arr(13); }     // the camera ray's hit record, kept from the pixel's first sample (FrameParams::camReuse)
-    __host__ __device__ __forceinline__ uint32_t* statBox() const { return (uint32_t*)arr(14); }             // stats[0] of the pixel (main-path traversals only)
-    __host__ __device__ __forceinline__ uint32_t* statTri() const { return (uint32_t*)arr(14) + pitchStat; } // stats[1]
+    __host__ __device__ __forceinline__ float4* camDir() const { return arr(14); }     // the camera ray's direction (every sample of the pixel starts with it: no jitter, raytrace.comp:541-557)
+    __host__ __device__ __forceinline__ uint32_t* statBox() const { return (uint32_t*)arr(15); }             // stats[0] of the pixel (main-path traversals only)
+    __host__ __device__ __forceinline__ uint32_t* statTri() const { return (uint32_t*)arr(15) + pitchStat; } // stats[1]
 };
 
 struct Queues {
@@ -159,6 +160,19 @@ struct FrameParams {
 struct DevCounters {
     unsigned long long boxTests, triTests, raysTraced, raysHit, raysReference, paths, segments, emitterTests;
 };
+
+// ---------------------------------------------------------------- address spaces of the scene tables
+// The shading code of k_render_fused reaches the scene through a pointer to the kernel-argument segment that the compiler
+// cannot see through (opaque_kernarg), so a table pointer read from it is a generic pointer to the compiler and every load
+// through it a FLAT instruction. Two statements of fact put that right (address-space inference does the rest after inlining):
+//   rt_uniform(p): read-only during the kernel and indexed the same by every lane of a wave (the emitter list, the spheres,
+//                  frame constants) -> constant address space -> scalar loads through the scalar cache, which keeps them off
+//                  the vector memory pipeline that the traversal saturates;
+//   rt_global(p):  read-only tables indexed per lane (materials, objects, triangles) -> global address space -> global_load.
+#define RT_AS_CONSTANT __attribute__((address_space(4)))
+#define RT_AS_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ const T* rt_uniform(const T* p) { return (const T*)(const RT_AS_CONSTANT T*)(unsigned long long)p; }
+template <typename T> __device__ __forceinline__ const T* rt_global(const T* p) { return (const T*)(const RT_AS_GLOBAL T*)(unsigned long long)p; }
 
 // ---------------------------------------------------------------- small helpers
 __device__ __forceinline__ rt_vec3 f4xyz(float4 v) { return rt_v3(v.x, v.y, v.z); }
@@ -263,11 +277,11 @@ __device__ __forceinline__ float4 sphere_seed(const DevScene& sc, rt_vec3 ro, rt
     for (uint32_t m = sc.sphereTestMask; m; m &= m - 1u) {  // ascending, as the shader's loop; repeats of an earlier sphere left out
         const uint32_t i = (uint32_t)__ffs((int)m) - 1u;
         if (i >= sc.sphereCount) break;
-        SphereHit h = sphere_intersect(sc.spheres[i], ro, rd);
+        SphereHit h = sphere_intersect(rt_uniform(sc.spheres)[i], ro, rd);
         if (h.didHit && h.dst < best) { best = h.dst; obj = RT_HIT_SPHERE | i; }
     }
     for (uint32_t i = 32; i < sc.sphereCount; i++) {  // beyond the mask (the reference has ten spheres)
-        SphereHit h = sphere_intersect(sc.spheres[i], ro, rd);
+        SphereHit h = sphere_intersect(rt_uniform(sc.spheres)[i], ro, rd);
         if (h.didHit && h.dst < best) { best = h.dst; obj = RT_HIT_SPHERE | i; }
     }
     return make_float4(best, __uint_as_float(obj), __uint_as_float(withMask ? reach_mask(sc, ro, rd) : 0xffffffffu), 0.f);
@@ -354,7 +368,7 @@ __device__ __forceinline__ void emitter_min_t2(const DevScene& sc, rt_vec3 ro, r
     for (uint32_t m = sc.emitSphereMask; m; m &= m - 1u) {
         const uint32_t i = (uint32_t)__ffs((int)m) - 1u;
         if (i >= sc.sphereCount) break;
-        const float4 s = sc.spheres[i];
+        const float4 s = rt_uniform(sc.spheres)[i];
         const SphereHit hA = sphere_intersect(s, ro, rdA), hB = sphere_intersect(s, ro, rdB);
         if (hA.didHit && hA.dst < tA) tA = hA.dst;
         if (hB.didHit && hB.dst < tB) tB = hB.dst;
@@ -363,16 +377,18 @@ __device__ __forceinline__ void emitter_min_t2(const DevScene& sc, rt_vec3 ro, r
     uint32_t curObj = 0xffffffffu;
     rt_vec3 tro = ro, trdA = rdA, trdB = rdB;
     for (uint32_t k = 0; k < sc.emitCount; k++) {
-        const uint32_t o = sc.emitTris[k].x;
+        const uint32_t o = rt_uniform(sc.emitTris)[k].x;
         if (o >= sc.objectCount) break;  // a dispatch with fewer objects than were uploaded (sorted by object)
         if (o != curObj) {
             curObj = o;
-            const float4 i0 = sc.objInv[3 * curObj], i1 = sc.objInv[3 * curObj + 1], i2 = sc.objInv[3 * curObj + 2];
+            const float4* inv = rt_uniform(sc.objInv) + 3 * curObj;
+            const float4 i0 = inv[0], i1 = inv[1], i2 = inv[2];
             trdA = xform_dir_rows(i0, i1, i2, rdA);
             trdB = xform_dir_rows(i0, i1, i2, rdB);
             tro = xform_point_rows(i0, i1, i2, ro);
         }
-        const float4 p0 = sc.emitPre[4 * k], p1 = sc.emitPre[4 * k + 1], p2 = sc.emitPre[4 * k + 2], p3 = sc.emitPre[4 * k + 3];
+        const float4* pre = rt_uniform(sc.emitPre) + 4 * k;
+        const float4 p0 = pre[0], p1 = pre[1], p2 = pre[2], p3 = pre[3];
         const rt_vec3 rov0 = rt_sub(tro, f4xyz(p0)), n = f4xyz(p3);
         const float rn = rt_dot(rov0, n);
         const bool frontOnly = __float_as_uint(p0.w) != 0u;
@@ -947,19 +963,19 @@ struct FullHit {
 __device__ __forceinline__ rt_vec3 albedo_texel(const DevScene& sc, uint32_t slot, uint32_t tri, uint32_t obj, rt_vec3 ro, rt_vec3 rd) {
     float bu, bv, bw;
     {
-        const float4 i0 = sc.objInv[3 * obj], i1 = sc.objInv[3 * obj + 1], i2 = sc.objInv[3 * obj + 2];
-        const float4 p0 = sc.triPos[3 * (size_t)tri], p1 = sc.triPos[3 * (size_t)tri + 1], p2 = sc.triPos[3 * (size_t)tri + 2];
+        const float4 i0 = rt_global(sc.objInv)[3 * obj], i1 = rt_global(sc.objInv)[3 * obj + 1], i2 = rt_global(sc.objInv)[3 * obj + 2];
+        const float4 p0 = rt_global(sc.triPos)[3 * (size_t)tri], p1 = rt_global(sc.triPos)[3 * (size_t)tri + 1], p2 = rt_global(sc.triPos)[3 * (size_t)tri + 2];
         const TriHit h = tri_intersect(xform_point_rows(i0, i1, i2, ro), xform_dir_rows(i0, i1, i2, rd), f4xyz(p0), f4xyz(p1), f4xyz(p2), __float_as_uint(p0.w) != 0u);
         bu = h.u; bv = h.v; bw = h.w;
     }
-    const float4 a = sc.triUV[2 * (size_t)tri], b = sc.triUV[2 * (size_t)tri + 1];  // {u0 v0 u1 v1} {u2 v2}
+    const float4 a = rt_global(sc.triUV)[2 * (size_t)tri], b = rt_global(sc.triUV)[2 * (size_t)tri + 1];  // {u0 v0 u1 v1} {u2 v2}
     float u = (bw * a.x + bu * a.z) + bv * b.x, v = (bw * a.y + bu * a.w) + bv * b.y;
     const bool e01 = a.x == a.z && a.y == a.w, e12 = a.z == b.x && a.w == b.y, e20 = b.x == a.x && b.y == a.y;
     if (e01 || e12 || e20) { u = 0.5f; v = 0.5f; }
-    const uint4 ti = sc.texInfo[slot];
-    const bool clampEdge = ((sc.objMeta[obj].w >> 16) & 0xffffu) == 1u;
+    const uint4 ti = rt_global(sc.texInfo)[slot];
+    const bool clampEdge = ((rt_global(sc.objMeta)[obj].w >> 16) & 0xffffu) == 1u;
     const uint32_t x = rt_tex_index(u, ti.y, clampEdge), y = rt_tex_index(1.f - v, ti.z, clampEdge);
-    const uint32_t t = sc.texels[(size_t)ti.x + (size_t)y * ti.y + x];
+    const uint32_t t = rt_global(sc.texels)[(size_t)ti.x + (size_t)y * ti.y + x];
     return rt_v3(rt_srgb8_to_linear(t & 0xffu), rt_srgb8_to_linear((t >> 8) & 0xffu), rt_srgb8_to_linear((t >> 16) & 0xffu));
 }
 
@@ -967,33 +983,37 @@ __device__ __forceinline__ FullHit reconstruct_hit(const DevScene& sc, rt_vec3 r
     FullHit f;
     if (obj & RT_HIT_SPHERE) {
         uint32_t i = obj & ~RT_HIT_SPHERE;
-        float4 s = sc.spheres[i];
+        float4 s = rt_global(sc.spheres)[i];
         SphereHit h = sphere_intersect(s, ro, rd);
         f.hitPoint = rt_add(ro, rt_scale(rd, h.dst));
         f.normal = rt_scale(rt_normalize(rt_sub(f.hitPoint, f4xyz(s))), h.frontFace ? 1.f : -1.f);
-        f.materialIndex = sc.sphereMat[i];
+        f.materialIndex = rt_global(sc.sphereMat)[i];
         f.frontFace = h.frontFace;
         return f;
     }
-    float4 i0 = sc.objInv[3 * obj], i1 = sc.objInv[3 * obj + 1], i2 = sc.objInv[3 * obj + 2];
-    float4 m0 = sc.objFwd[3 * obj], m1 = sc.objFwd[3 * obj + 1], m2 = sc.objFwd[3 * obj + 2];
+    const float4* inv = rt_global(sc.objInv) + 3 * obj;
+    float4 i0 = inv[0], i1 = inv[1], i2 = inv[2];
+    const float4* fwd = rt_global(sc.objFwd) + 3 * obj;
+    float4 m0 = fwd[0], m1 = fwd[1], m2 = fwd[2];
     rt_vec3 trd = xform_dir_rows(i0, i1, i2, rd);
     rt_vec3 tro = xform_point_rows(i0, i1, i2, ro);
-    float4 a = sc.triPos[3 * (size_t)tri], b = sc.triPos[3 * (size_t)tri + 1], c = sc.triPos[3 * (size_t)tri + 2];
+    const float4* tp = rt_global(sc.triPos) + 3 * (size_t)tri;
+    float4 a = tp[0], b = tp[1], c = tp[2];
     TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
-    rt_vec3 n0 = f4xyz(sc.triNrm[3 * (size_t)tri]), n1 = f4xyz(sc.triNrm[3 * (size_t)tri + 1]), n2 = f4xyz(sc.triNrm[3 * (size_t)tri + 2]);
+    const float4* tn = rt_global(sc.triNrm) + 3 * (size_t)tri;
+    rt_vec3 n0 = f4xyz(tn[0]), n1 = f4xyz(tn[1]), n2 = f4xyz(tn[2]);
     rt_vec3 ni = rt_add(rt_add(rt_scale(n0, h.w), rt_scale(n1, h.u)), rt_scale(n2, h.v));
     ni = rt_scale(ni, h.frontFace ? 1.f : -1.f);
     rt_vec3 op = rt_add(tro, rt_scale(trd, h.dst));
     f.normal = rt_normalize(xform_dir_rows(m0, m1, m2, ni));
     f.hitPoint = xform_point_rows(m0, m1, m2, op);
-    f.materialIndex = sc.objMeta[obj].z;
+    f.materialIndex = rt_global(sc.objMeta)[obj].z;
     f.frontFace = h.frontFace;
     return f;
 }
 
 __device__ __forceinline__ uint32_t hit_material(const DevScene& sc, uint32_t obj) {
-    return (obj & RT_HIT_SPHERE) ? sc.sphereMat[obj & ~RT_HIT_SPHERE] : sc.objMeta[obj].z;
+    return (obj & RT_HIT_SPHERE) ? rt_global(sc.sphereMat)[obj & ~RT_HIT_SPHERE] : rt_global(sc.objMeta)[obj].z;
 }
 
 // ---------------------------------------------------------------- shading pieces
@@ -1023,7 +1043,7 @@ __device__ __forceinline__ rt_vec3 environment_light(const EnvironmentData& env,
 __device__ __forceinline__ float light_sample_pdf(const DevScene& sc, float t, uint32_t obj, rt_vec3 dir) {
     if (obj == RT_HIT_NONE) return 0.f;
     uint32_t m = hit_material(sc, obj);
-    if (sc.mats[3 * m + 1].w == 0.f) return 0.f;
+    if (rt_global(sc.mats)[3 * m + 1].w == 0.f) return 0.f;
     float sq = t * t;
     float cosTheta = rt_dot(rt_v3(0.f, -1.f, 0.f), dir);
     return sq / (cosTheta * 0.4444444f);
@@ -1080,6 +1100,7 @@ __device__ __forceinline__ void init_path(const DevScene& sc, const PathState& p
         startingSeed = (uint32_t)(rt_random(&lol) * 23892183.f);
     }
     ps.rayD()[slot] = mk4u(pd, gy * fp.width + gx + startingSeed);                                      // RNG seed (:564)
+    ps.camDir()[slot] = mk4(pd, 0.f);
     ps.hit(RAY_MAIN)[slot] = sphere_seed(sc, rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]), pd);
     ps.att()[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));                                   // j = 0
     ps.total()[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));                                 // sample 0
@@ -1149,7 +1170,7 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
             uint32_t oL = __float_as_uint(hL.y), oC = __float_as_uint(hC.y);
             rt_vec3 dL = f4xyz(aL), dC = f4xyz(aC);
             uint32_t lm = (oL == RT_HIT_NONE) ? 0u : hit_material(sc, oL);
-            float4 lmE = sc.mats[3 * lm + 1];
+            float4 lmE = rt_global(sc.mats)[3 * lm + 1];
             float realLightPDF = light_sample_pdf(sc, tL, oL, dL);
             float cosinePDF = aL.w;
             float misWeight1 = realLightPDF * realLightPDF / (realLightPDF * realLightPDF + cosinePDF * cosinePDF);
@@ -1167,7 +1188,8 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
         }
 
         FullHit hit = reconstruct_hit(sc, ro, rd, obj, hitTriIdx);
-        float4 mA = sc.mats[3 * hit.materialIndex], mE = sc.mats[3 * hit.materialIndex + 1], mI = sc.mats[3 * hit.materialIndex + 2];
+        const float4* mp = rt_global(sc.mats) + 3 * hit.materialIndex;
+        float4 mA = mp[0], mE = mp[1], mI = mp[2];
 
         // 0-1 NEE (:501-505)
         rt_vec3 emission = rt_scale(rt_v3(mE.x, mE.y, mE.z), mE.w);
@@ -1267,11 +1289,10 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
         ps.accum()[slot] = mk4(sum, 0.f);
         samplesDone++;
         if (samplesDone < fp.samples) {
-            // next sample of this pixel: same primary ray, RNG state runs on (:571-573)
-            uint32_t gx, gy, krow;
-            slot_to_pixel(fp, slot, gx, gy, krow);
+            // next sample of this pixel: same primary ray (kept by init_path rather than derived from the slot again: the
+            // whole wave pays for this branch whenever one lane finishes a sample), RNG state runs on (:571-573)
             ro = rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]);
-            rd = primary_dir(fp, gx, gy);
+            rd = f4xyz(ps.camDir()[slot]);
             att = rt_v3(1.f, 1.f, 1.f);
             total = rt_v3(0.f, 0.f, 0.f);
             direct = rt_v3(0.f, 0.f, 0.f);
@@ -1454,8 +1475,7 @@ template <typename T>
 __device__ __forceinline__ const T* opaque_kernarg() {
     unsigned long long v = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(v));
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return (const T*)(((unsigned long long)hi << 32) | lo);
+    return (const T*)(const RT_AS_CONSTANT T*)v;  // constant address space: what is read through it are scalar loads (a plain generic pointer made them FLAT vector loads)
 }
 
 struct FusedKernArgs {  // the whole kernel-argument segment, so that it can be addressed as memory
