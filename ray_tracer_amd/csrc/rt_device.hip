@@ -931,6 +931,7 @@ extern "C" {
 }  // extern "C"
 
 namespace {
+#define RT_FRAMES_MAX_SLOTS (16ull << 20)   // paths of one multi-frame dispatch (two 4K frames' worth)
 // rt_render (nFrames = 1) and rt_render_frames
 int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t height, uint32_t row0, uint32_t rowStride,
                 uint32_t nRows, uint32_t nFrames, float* d_rgba) {
@@ -996,6 +997,9 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
     c->sc = sc;
 
     const uint32_t blocksPix = (nPixels + RT_BLOCK - 1) / RT_BLOCK;
+    // several frames in one dispatch: the paths are {64 tile slots} x {frames} (FrameParams::nFrames), in either pipeline
+    const uint32_t nSlots = nFrames > 1u ? (nPixels + 63u) / 64u * 64u * nFrames : nPixels;
+    const uint32_t blocksSlots = (nSlots + RT_BLOCK - 1) / RT_BLOCK;
     DevCounters* dc = (DevCounters*)c->counterBuf.p;
     uint32_t* counts = c->q.counts;
 
@@ -1014,8 +1018,8 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
     // near 2 M (1/8 of a 4K frame: 85 against 94; 1/4: 162 against 159)
     double sizeLimit = (double)c->fusedBelowPixels;
     if (c->boxPerRay > 160.0) sizeLimit = std::max(800000.0, sizeLimit - (c->boxPerRay - 160.0) * 75000.0);
-    c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (((double)nPixels < sizeLimit || shortRays) ? 1 : 0);
-    if (nFrames > 1u) c->lastPipeline = 1;  // several frames in one launch exist in the fused kernel only (rt_render_frames decides)
+    // (the paths of all the frames of the dispatch count: four frames of a quarter of a 4K frame are a 4K frame's worth)
+    c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (((double)nSlots < sizeLimit || shortRays) ? 1 : 0);
     if (c->lastPipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch
         rc = launch_fused(c, fp, fb);
         if (!rc && nFrames > 1u) {
@@ -1025,19 +1029,19 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
         if (!rc) request_ray_cost(c);
         return rc;
     }
-    hipLaunchKernelGGL(k_raygen, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, c->q, fp);
+    hipLaunchKernelGGL(k_raygen, dim3(blocksSlots), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, c->q, fp);
     RT_HIP(c, hipGetLastError());
 
     if (fp.samples > 0) {
         // counts: [0],[1] active paths of buffer 0/1; [2],[3] rays of buffer 0/1; [4] the traversal's work counter
-        hipLaunchKernelGGL(k_init_counts, dim3(1), dim3(64), 0, c->stream, counts, nPixels);
+        hipLaunchKernelGGL(k_init_counts, dim3(1), dim3(64), 0, c->stream, counts, nSlots);
 
         // The whole dispatch is enqueued without waiting for the device (rt_amd.h: "asynchronous on the ctx stream"): every
         // kernel reads its queue length from device memory and leaves at once when the queue is empty, so the loop may
         // simply run to the most rounds a pixel can need, samples * (bounceLimit + 1). The active-path count is copied
         // back now and then without ever being waited for; a copy that has arrived shrinks the grids of the launches still
         // to be enqueued (active paths never increase, so a stale count is a valid upper bound) and ends the loop at zero.
-        uint32_t ubActive = nPixels;
+        uint32_t ubActive = nSlots;
         int cur = 0;
         const uint64_t maxRounds = (uint64_t)fp.samples * ((uint64_t)fp.bounceLimit + 1);
         bool pollPending = false;
@@ -1045,7 +1049,7 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
             const int nxt = cur ^ 1;
             hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, c->stream, counts + nxt, counts + 2 + nxt, counts + 4);
             TraceArgs ta{c->q.rays[cur], counts + 2 + cur, nullptr, nullptr, dc};
-            uint64_t ubRays = std::min<uint64_t>((uint64_t)ubActive * 3, (uint64_t)nPixels * 3);
+            uint64_t ubRays = std::min<uint64_t>((uint64_t)ubActive * 3, (uint64_t)nSlots * 3);
             if ((rc = launch_trace(c, (uint32_t)ubRays, ta))) return rc;
             ShadeArgs sa{c->q.active[cur], counts + cur, c->q.active[nxt], c->q.rays[nxt], counts + nxt, counts + 2 + nxt, dc};
             hipLaunchKernelGGL(k_shade, dim3((ubActive + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, sa, fp);
@@ -1064,7 +1068,8 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
         // (a copy still in flight when the loop ends is harmless: the stream orders it before the next dispatch's own
         // copies, and the slot is only read after the event of the copy that filled it)
     }
-    hipLaunchKernelGGL(k_resolve, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->ps, fp, fb);
+    if (nFrames > 1u) hipLaunchKernelGGL(k_blend_frames, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->ps, fp, fb);
+    else hipLaunchKernelGGL(k_resolve, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->ps, fp, fb);
     RT_HIP(c, hipGetLastError());
     request_ray_cost(c);
     return 0;
@@ -1082,19 +1087,15 @@ int rt_render_frames(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_
                      uint32_t nRows, uint32_t nFrames, float* d_rgba) {
     if (!c || !pc) return -1;
     if (nFrames == 0) return 0;
-    // One launch for all the frames when the fused pipeline would render each of them anyway (forced, or the automatic
-    // choice for one frame of this tile: small tiles and short rays, the cases that leave a GPU short of pixels) and the
-    // frames are ordinary ones (no heat maps: those read per-pixel counters at resolve time). Otherwise frame by frame.
+    // The frames of one call are one dispatch: their paths share the launch (fused pipeline) or the queues of every round
+    // (multi-kernel pipeline; render_impl picks the pipeline by the paths of all the frames together, so four frames of a
+    // quarter of a 4K frame run like a whole 4K frame). Ordinary frames only (no heat maps: those read per-pixel counters at
+    // resolve time), within the 30-bit slot ids and RT_FRAMES_MAX_SLOTS paths (3.9 GB of path state); more frames than that
+    // go in several dispatches.
     const uint64_t np = (uint64_t)nRows * width;
-    const bool shortRays = c->boxPerRay >= 0.0 && c->boxPerRay < (double)c->fusedBelowBoxTests;
-    double sizeLimit = (double)c->fusedBelowPixels;
-    if (c->boxPerRay > 160.0) sizeLimit = std::max(800000.0, sizeLimit - (c->boxPerRay - 160.0) * 75000.0);
-    const bool fusedOne = c->pipeline == 1 || (c->pipeline < 0 && ((double)np < sizeLimit || shortRays));
-    uint32_t per = 1;  // frames per launch
-    if (fusedOne && nFrames > 1u && pc->rayTraceParams.debug < 0 && np > 0) {
-        // as many frames per launch as keep the launch below the size at which one frame would leave the fused pipeline,
-        // and within the 30-bit slot ids
-        const uint64_t cap = std::min<uint64_t>((uint64_t)std::max(sizeLimit, (double)np), (1ull << 30) - 1);
+    uint32_t per = 1;  // frames per dispatch
+    if (nFrames > 1u && pc->rayTraceParams.debug < 0 && np > 0) {
+        const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(RT_FRAMES_MAX_SLOTS, np), (1ull << 30) - 1);
         per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nFrames, cap / ((np + 63) / 64 * 64)));
         if (c->framesPerLaunch > 0) per = std::min(per, (uint32_t)c->framesPerLaunch);
     }

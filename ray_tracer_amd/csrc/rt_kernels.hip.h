@@ -442,7 +442,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * STACK * RT_WAVE];
     const uint32_t n = *ta.count;
     const uint32_t gid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const bool live = gid < n;
+    const bool live = gid < n && !(ta.queue && ta.queue[gid] == 0xffffffffu);  // RT_QUEUE_HOLE
     if (__ballot(live) == 0ull) return;
 
     uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * STACK * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
@@ -696,7 +696,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     if (rk < take) {
                         qidx = resBase + rk;
                         id = LOCAL ? localList[qidx] : (ta.queue ? ta.queue[qidx] : (qidx << 2));
-                        cur = RT_CUR_INIT;
+                        cur = (!LOCAL && id == 0xffffffffu) ? RT_CUR_IDLE : RT_CUR_INIT;  // RT_QUEUE_HOLE: no ray behind this entry (k_raygen)
                     }
                 }
                 resBase += take;
@@ -1110,9 +1110,17 @@ __device__ __forceinline__ void init_path(const DevScene& sc, const PathState& p
     ps.statTri()[slot] = 0;
 }
 
+#define RT_QUEUE_HOLE 0xffffffffu   // queue entry without a path (multi-frame dispatch: the padding of a tile that is not a multiple of 64 slots)
 __global__ __launch_bounds__(RT_BLOCK) void k_raygen(DevScene sc, PathState ps, Queues q, FrameParams fp) {
     uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (slot >= fp.nPixels) return;
+    // several frames per dispatch (rt_render_frames): the slots run over {64 tile slots} x {frames}, see FrameParams::nFrames
+    const uint32_t nSlots = fp.nFrames > 1u ? ((fp.nPixels + 63u) >> 6) * 64u * fp.nFrames : fp.nPixels;
+    if (slot >= nSlots) return;
+    if (fp.nFrames > 1u && slot_in_tile(fp, slot) >= fp.nPixels) {
+        q.active[0][slot] = RT_QUEUE_HOLE;
+        q.rays[0][slot] = RT_QUEUE_HOLE;
+        return;
+    }
     init_path(sc, ps, fp, slot);
     q.active[0][slot] = slot;
     q.rays[0][slot] = slot << 2;
@@ -1351,9 +1359,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
     uint32_t auxMask = 0;  // ... bit 0: and a NEE ray, bit 1: and a cosine probe
     uint32_t slot = 0;
     uint32_t refRays = 0, nPaths = 0, emitTests = 0;
+    bool path = live;
     if (live) {
         slot = sa.inActive[gid];
-        shade_path(sc, ps, fp, slot, alive, auxMask, refRays, nPaths, emitTests);
+        path = slot != 0xffffffffu;  // RT_QUEUE_HOLE
+        if (path) shade_path(sc, ps, fp, slot, alive, auxMask, refRays, nPaths, emitTests);
     }
 
     // Queue compaction: ranks inside a wave from ballots, wave offsets through LDS, and ONE atomic
@@ -1362,7 +1372,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
     const unsigned long long mAlive = __ballot(alive), mM = __ballot(alive && !(auxMask & 4u));
     const unsigned long long mL = __ballot(alive && (auxMask & 1u)), mC = __ballot(alive && (auxMask & 2u));
     const uint32_t nAlive = __popcll(mAlive), nM = __popcll(mM), nL = __popcll(mL), nC = __popcll(mC);
-    const uint32_t wRef = wave_sum_u32(refRays), wPaths = wave_sum_u32(nPaths), wSeg = wave_sum_u32(live ? 1u : 0u), wEmit = wave_sum_u32(emitTests);
+    const uint32_t wRef = wave_sum_u32(refRays), wPaths = wave_sum_u32(nPaths), wSeg = wave_sum_u32(path ? 1u : 0u), wEmit = wave_sum_u32(emitTests);
     const uint32_t wv = threadIdx.x / RT_WAVE;
     if (lane_id() == 0) {
         s_cnt[wv][0] = nAlive; s_cnt[wv][1] = nM + nL + nC; s_cnt[wv][2] = wRef; s_cnt[wv][3] = wPaths; s_cnt[wv][4] = wSeg; s_cnt[wv][5] = wEmit;
