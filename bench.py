@@ -52,10 +52,11 @@ def main():
                     help="send a one-rank job through the process group, gather and reductions too (RCCL smoke test on a one-GPU box)")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole frame alone and compares it with the gathered one")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="most steps (= progressive frames) a rank submits at once through rt_render_frames; 0 = 2 N on N GPUs: a 1/N "
-                         "tile has too few pixels to fill a GPU, because a pixel's samples are serial; N frames of it are one frame's "
-                         "worth of pixels, and a second frame's worth fills the first one's tail (-2.6 % on one GPU). The steps of a "
-                         "run are split into equal groups of at most that many. 1 = every step its own dispatch and its own gather")
+                    help="most steps (= progressive frames) a rank submits at once through rt_render_frames; 0 = 10 N on N GPUs. A pixel's "
+                         "samples are serial, so what fills a GPU is paths: N frames of a 1/N tile are one frame's worth, and the "
+                         "traversal gets cheaper per ray the more paths share a dispatch (Sponza 1080p, ms per step with 1 / 2 / 4 / 10 / 20 "
+                         "frames in one dispatch: 117 / 113.5 / 103.9 / 99.4 / 98.8). The steps of a run are split into equal groups of "
+                         "at most that many. 1 = every step its own dispatch and its own gather")
     args = ap.parse_args()
 
     import numpy as np
@@ -113,7 +114,7 @@ def main():
     # Steps are progressive frames: independent until they are blended in order. A rank may therefore submit a group of
     # them at once (rt_render_frames: their pixels share a launch, the blends follow in frame order — the same bits as
     # one dispatch per step); the strips are gathered once per group.
-    fif = args.frames_in_flight if args.frames_in_flight > 0 else 2 * world
+    fif = args.frames_in_flight if args.frames_in_flight > 0 else 10 * world
 
     def launch(i, n):
         pc.frameCount = i
@@ -146,8 +147,8 @@ def main():
         torch.cuda.synchronize()
 
     def groups(count):
-        """`count` steps in the fewest groups of at most `fif`, sized evenly (20 steps, at most 16 at once: 10 + 10, not 16 + 4 —
-        a small last group would leave the GPU half empty, which is what the groups are there to avoid)."""
+        """`count` steps in the fewest groups of at most `fif`, sized evenly (24 steps, at most 10 at once: 8 + 8 + 8, not
+        10 + 10 + 4 — a small last group would leave the GPU short of paths, which is what the groups are there to avoid)."""
         if count <= 0:
             return []
         k = (count + fif - 1) // fif

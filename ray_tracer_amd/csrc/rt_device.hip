@@ -29,6 +29,7 @@ struct DevBuf {
 
 struct EventPair { hipEvent_t a, b; };
 // device-side {index,triCount} of a mesh root, keyed by its reference node index
+#define RT_FRAMES_MAX_SLOTS (24ull << 20)   // default for the paths of one multi-frame dispatch (ten 1080p frames or three 4K frames: 5.8 GB of path state)
 struct RootInfo { uint32_t idx, cnt; float lo[3], hi[3]; uint32_t triFirst, triTotal; };  // triTotal = ~0u: the mesh's triangles are not one contiguous range
 
 }  // namespace
@@ -79,7 +80,8 @@ struct rt_ctx {
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
     int pipeline = -1;      // 0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline (k_render_fused), -1 = by tile size
     int lastPipeline = 0;   // what the last rt_render used
-    uint32_t fusedBelowPixels = 6000000;  // auto: tiles smaller than this use the fused pipeline (1080p and 1440p frames do, 4K does not)
+    uint32_t fusedBelowPixels = 4000000;  // auto: dispatches of fewer paths than this use the fused pipeline. Sponza, 8 spp, ms per step with 1 / 2 / 4 / 8
+                                          // frames of 1080p in one dispatch: fused 117 / 113.5 / 111.3 / 110.2, multi-kernel 131.4 / 113.5 / 103.9 / 99.9
     uint32_t fusedBelowBoxTests = 90;     // auto: ... and so do scenes whose rays are short (box tests per ray, measured)
     // box tests per ray of this scene, from counter snapshots copied back asynchronously after each dispatch
     DevCounters* snap = nullptr;          // pinned
@@ -89,6 +91,7 @@ struct rt_ctx {
     unsigned long long snapBox = 0, snapRays = 0;  // counters at the previous snapshot
     double boxPerRay = -1.0;              // < 0: not measured yet
     int refill = 8;         // k_trace_pw: idle lanes that trigger a refill
+    int refillMk = 16;      // the same for k_trace_pw over the global queue (ten frames of the bench frame in flight: 8 -> 99.1, 16 -> 96.6, 24 -> 97.9, 32 -> 99.3 ms per step)
     int chunk = 256;        // k_trace_pw: most queue entries reserved per atomic
     int ldsStackCap = 24;   // k_trace_pw: LDS stack entries per lane (8, 16 or 24); deeper BVHs use the overflow buffer
     int fastLanes = 32;     // k_trace_pw: lanes at interior nodes that skip the full vote (4K Sponza: 24 -> 32 is -2 %, 1080p: equal)
@@ -105,6 +108,7 @@ struct rt_ctx {
     bool cull = false;      // kernels with the object-skipping code (CULL) for this scene
     int maskIdentity = 0;   // identity-transform objects in the rays' object masks too (rt_update_objects reads it)
     int scatter = -1;       // fused pipeline: blocks made of chunks of this many slots from all over the tile; 0 = neighbouring pixels; -1 = auto
+    uint64_t framesMaxSlots = RT_FRAMES_MAX_SLOTS;  // most paths of one multi-frame dispatch (rt_render_frames)
     int pixelRefill = 0;    // fused pipeline: free lanes at which a wave reserves new pixels (64 = a block at a time, 0 = by ray length)
     int batchPixels = 0;    // fused pipeline: pixels per wave-private block (0 = chosen per launch)
     int batchFixed = 80;    // ... and the fixed part of a block's cost in the chooser, in pixel units
@@ -218,7 +222,7 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
         if (rc) return rc;
         waveTimes = (unsigned long long*)c->waveTimeBuf.p;
     }
-    TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refill, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, (uint32_t)c->fastShare,
+    TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refillMk, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, (uint32_t)c->fastShare,
                    ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), waveTimes, overflow};
     // per-ray counters are only needed for the pixel heat maps (debug >= 0) and rt_trace_rays
     const bool pix = c->pixStats || ta.perRayBox;
@@ -931,7 +935,6 @@ extern "C" {
 }  // extern "C"
 
 namespace {
-#define RT_FRAMES_MAX_SLOTS (16ull << 20)   // paths of one multi-frame dispatch (two 4K frames' worth)
 // rt_render (nFrames = 1) and rt_render_frames
 int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t height, uint32_t row0, uint32_t rowStride,
                 uint32_t nRows, uint32_t nFrames, float* d_rgba) {
@@ -1095,7 +1098,7 @@ int rt_render_frames(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_
     const uint64_t np = (uint64_t)nRows * width;
     uint32_t per = 1;  // frames per dispatch
     if (nFrames > 1u && pc->rayTraceParams.debug < 0 && np > 0) {
-        const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(RT_FRAMES_MAX_SLOTS, np), (1ull << 30) - 1);
+        const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(c->framesMaxSlots, np), (1ull << 30) - 1);
         per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nFrames, cap / ((np + 63) / 64 * 64)));
         if (c->framesPerLaunch > 0) per = std::min(per, (uint32_t)c->framesPerLaunch);
     }
@@ -1251,13 +1254,15 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     std::string k(key);
     if (k == "pipeline") { if (value < -1 || value > 1) return c->fail("pipeline: -1 (auto), 0 or 1"); c->pipeline = value; }
     else if (k == "probe") { c->probe = value ? 1 : 0; }
+    else if (k == "frames_max_mslots") { if (value < 1 || value > 1000) return c->fail("frames_max_mslots: 1..1000 (millions of paths per multi-frame dispatch)"); c->framesMaxSlots = (uint64_t)value << 20; }
     else if (k == "frames_per_launch") { if (value < 0) return c->fail("frames_per_launch >= 0"); c->framesPerLaunch = value; }
     else if (k == "camera_reuse") { c->cameraReuse = value ? 1 : 0; }
     else if (k == "light_queries") { c->lightQueries = value ? 1 : 0; int rc = rebuild_emitters(c); if (rc) return rc; }
     else if (k == "fused_below_box_tests") { if (value < 0) return c->fail("fused_below_box_tests >= 0"); c->fusedBelowBoxTests = (uint32_t)value; }
     else if (k == "fused_below_pixels") { if (value < 0) return c->fail("fused_below_pixels >= 0"); c->fusedBelowPixels = (uint32_t)value; }
     else if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
-    else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; }
+    else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; c->refillMk = value; }
+    else if (k == "mk_refill") { if (value < 1 || value > 64) return c->fail("mk_refill: 1..64"); c->refillMk = value; }
     else if (k == "lds_stack") { if (value != 8 && value != 16 && value != 24) return c->fail("lds_stack: 8, 16 or 24"); c->ldsStackCap = value; }
     else if (k == "fast_lanes") { if (value < 0 || value > 65) return c->fail("fast_lanes: 1..65 (0: back to the defaults)"); c->fastLanesSet = value != 0; c->fastLanes = value ? value : 32; }
     else if (k == "chunk") { if (value < 1 || value > 4096) return c->fail("chunk: 1..4096"); c->chunk = value; }

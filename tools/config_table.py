@@ -36,7 +36,7 @@ for name, key, W, H, spp, per in CONFIGS:
         r.sync()
         t = time.perf_counter()
         i, n = 0, spp // per
-        fif = 2 * world                      # as bench.py: at most 2 N dispatches (progressive frames) in flight on one of N GPUs
+        fif = 10 * world                     # as bench.py: at most 10 N dispatches (progressive frames) in flight on one of N GPUs
         ng = (n + fif - 1) // fif            # (rt_render_frames), in even groups
         sizes = [n // ng + (1 if j < n % ng else 0) for j in range(ng)]
         for k in sizes:
