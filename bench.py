@@ -230,8 +230,9 @@ def main():
                       "effective_clock_ghz"):
                 if k in pm:
                     rf[k] = pm[k]
-            rf["bound_by_counters"] = ("vector memory pipeline (TA busy) and VALU issue together, not HBM: the algorithmic bytes are mostly "
-                                       "served by L1 / L2 (traffic << algorithmic), see DESIGN.md section 6")
+            if "ta_busy_frac" in rf and "valu_issue_frac" in rf:
+                rf["bound_by_counters"] = (f"vector memory pipeline (TA busy {rf['ta_busy_frac'] * 100:.0f} %), then VALU issue ({rf['valu_issue_frac'] * 100:.0f} %), "
+                                           "not HBM: the algorithmic bytes are mostly served by L1 / L2 (traffic << algorithmic), see DESIGN.md section 6")
         if world == 1:
             # the nominal peak and a streaming copy measured on this very box (1 GiB, read + write), both quoted
             out["roofline"]["measured_copy_gbps"] = r.copy_bandwidth_gbps(1 << 30, 5)
