@@ -566,6 +566,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
 //     (bit-identical to multiplying by the identity when no component is
 //     zero, negative-zero or non-finite; other rays take the general path).
 //     The next object's metadata is fetched one object ahead.
+#define RT_META_LDS 128u           // objects whose {root word, flags} a work-group keeps in LDS (1 KB)
 #define RT_CUR_IDLE 0xffffffffu   // no ray
 #define RT_CUR_NEED 0xfffffffeu   // wants its next node (tail)
 #define RT_CUR_SETUP 0xfffffffdu  // entering object `obj`, which has a general transform
@@ -615,7 +616,7 @@ struct WaveTotals {
 // path that is only entered when fewer than `fastLanes` lanes are at interior nodes.
 template <int STACK, bool OVF, bool PIX, bool STATS, bool LOCAL, bool CULL>
 __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& ps, const TracePwArgs& ta, uint32_t* stack, uint32_t* ovf,
-                                           size_t ovfStride, const uint32_t* localList, uint32_t n, WaveTotals& wt) {
+                                           size_t ovfStride, const uint32_t* localList, uint32_t n, WaveTotals& wt, const uint2* metaLds) {
     uint32_t cur = RT_CUR_IDLE;
     uint32_t id = 0, qidx = 0;
     // ray in the current object's space and 1/dir (written by the setup step only); x and y are kept as
@@ -655,8 +656,15 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
         }
         uint32_t fl = 0;
         if (obj < sc.objectCount) {
-            const uint4 m = sc.objMeta[obj];
-            nxW = m.x; fl = m.w & 0xffu;
+            // {root word, flags} of the next object: from the work-group's LDS copy (metaLds: the first RT_META_LDS objects) — one
+            // vector load per object and ray less on the memory pipeline that bounds the traversal (Sponza: 26 of ~400 per ray)
+            if (!CULL && obj < RT_META_LDS) {   // (not in the CULL instantiations: see the note at fill_meta_lds)
+                const uint2 m = metaLds[obj];
+                nxW = m.x; fl = m.y;
+            } else {
+                const uint4 m = sc.objMeta[obj];
+                nxW = m.x; fl = m.w & 0xffu;
+            }
         }
         nxFlags = CULL ? (fl | (skip << 8)) : fl;
     };
@@ -915,16 +923,35 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
 
 }
 
+// the work-group's LDS copy of the first RT_META_LDS objects' {root word, flags} (fetch_next_meta). Scenes of identity-transform
+// objects only (the CULL = false instantiations: Sponza and the flattened C5, where a ray walks through every object's root):
+// with it the instantiation k_render_fused<24, false, false, true> rendered wrong frames (Cornell + bunny stand-in, klein
+// bottle: thousands of pixels, fewer rays traced) while k_trace_pw with the same trace_wave and every other fused instantiation
+// stayed bit-identical to the oracle — the second time that very instantiation (69 spilled SGPRs) came out wrong after an edit
+// that is right in the source (profiles/README.md); the scenes it serves have ten objects, so nothing is lost by leaving it out.
+template <bool CULL>
+__device__ __forceinline__ void fill_meta_lds(const DevScene& sc, uint2* s_meta) {
+    if (CULL) return;
+    if (threadIdx.x < RT_META_LDS) {
+        uint2 m = make_uint2(0u, 0u);
+        if (threadIdx.x < sc.objectCount) { const uint4 q = sc.objMeta[threadIdx.x]; m = make_uint2(q.x, q.w & 0xffu); }
+        s_meta[threadIdx.x] = m;
+    }
+    __syncthreads();
+}
+
 template <int STACK, bool OVF, bool PIX, bool STATS, bool CULL>
 __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];  // +1: pushes are unconditional
+    __shared__ uint2 s_meta[CULL ? 1 : RT_META_LDS];
+    fill_meta_lds<CULL>(sc, s_meta);
     uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
     // overflow entries of this lane: index k at ovf[k * ovfStride]
     uint32_t* ovf = OVF ? ta.overflow + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x : nullptr;
     const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
     WaveTotals wt;
     const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
-    trace_wave<STACK, OVF, PIX, STATS, false, CULL>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt);
+    trace_wave<STACK, OVF, PIX, STATS, false, CULL>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt, s_meta);
 
     if (STATS && lane_id() == 0) {
         const size_t w = (size_t)blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;
@@ -1509,9 +1536,11 @@ __global__ __launch_bounds__(RT_BLOCK, PIX ? 4 : 5) void k_render_fused(FusedKer
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];
     __shared__ uint32_t s_list[RT_BLOCK / RT_WAVE][3 * RT_WAVE];
     __shared__ float4 s_box[64];  // DevScene::maskBox (the objects of the mask's window that can be ruled out): the rays' object masks are computed from here (reach_mask_from)
+    __shared__ uint2 s_meta[CULL ? 1 : RT_META_LDS];
     const uint32_t nBox = CULL ? sc.reachCount : 0u;
     if (CULL && threadIdx.x < 2u * nBox) s_box[threadIdx.x] = sc.maskBox[threadIdx.x];
-    __syncthreads();
+    fill_meta_lds<CULL>(sc, s_meta);
+    if (CULL) __syncthreads();
     const uint32_t wv = threadIdx.x / RT_WAVE;
     uint32_t* stack = s_stack + wv * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
     uint32_t* list = s_list[wv];
@@ -1583,7 +1612,7 @@ __global__ __launch_bounds__(RT_BLOCK, PIX ? 4 : 5) void k_render_fused(FusedKer
         }
         const uint32_t nRays = nM + nL + nC;
         __threadfence_block();  // the rays written by shade_path / init_path are read by other lanes of this wave
-        trace_wave<STACK, OVF, PIX, false, true, CULL>(sc, ps, ta, stack, ovf, ovfStride, list, nRays, wt);
+        trace_wave<STACK, OVF, PIX, false, true, CULL>(sc, ps, ta, stack, ovf, ovfStride, list, nRays, wt, s_meta);
         __threadfence_block();  // ... and so are the hit records
         if (alive) {
             bool nowAlive = false;
