@@ -242,14 +242,20 @@ def main():
             out["cpu_baseline"], ref_rows, tile = cpu_baseline(scene, pc, W, H, args)
             # the rows the oracle has just rendered are the rows of the bench frame at frameCount 0: render them on the
             # GPU with the same constants and compare, bit for bit (the oracle is the checker here, never the product)
-            r.reset_counters()
-            pc.frameCount = 0
-            gpu_rows = r.render(pc, W, H, **tile)
-            same = bool(np.array_equal(gpu_rows.view(np.uint32), ref_rows.view(np.uint32)))
-            with np.errstate(all="ignore"):
-                rel = np.abs(gpu_rows - ref_rows) / np.maximum(np.abs(ref_rows), 1e-6)
+            # ... through both pipelines (the timed groups run in one of them, small tiles in the other)
+            same, max_rel = True, 0.0
+            for pipe in (0, 1):
+                r.set_tuning("pipeline", pipe)
+                r.reset_counters()
+                pc.frameCount = 0
+                gpu_rows = r.render(pc, W, H, **tile)
+                same = same and bool(np.array_equal(gpu_rows.view(np.uint32), ref_rows.view(np.uint32)))
+                with np.errstate(all="ignore"):
+                    rel = np.abs(gpu_rows - ref_rows) / np.maximum(np.abs(ref_rows), 1e-6)
+                max_rel = max(max_rel, float(np.nanmax(rel)) if rel.size else 0.0)
+            r.set_tuning("pipeline", -1)
             out["parity_check"] = {"rows": tile["nRows"], "pixels": int(tile["nRows"] * W), "spp": args.spp, "equal": same,
-                                   "max_rel": float(np.nanmax(rel)) if rel.size else 0.0,
+                                   "max_rel": max_rel, "pipelines": ["multi-kernel", "fused"],
                                    "against": "oracle (scalar restatement of raytrace.comp), same rows, frameCount 0"}
         if args.check and multi:
             # the same frames rendered by one process must equal the stitched strips bit for bit
