@@ -303,10 +303,13 @@ int  rt_render(rt_ctx* ctx, const PushConstants* pc, uint32_t width, uint32_t he
 /* nFrames consecutive progressive dispatches of the same tile — the same pixels, bit for bit, as nFrames calls of rt_render
  * with frameCount = pc->frameCount, pc->frameCount + 1, ... (the reference's frame loop, src/vk_engine.cpp:1782-1814, runs them
  * one after the other and waits for each). Frames are independent until they are blended (each has its own RNG seeds,
- * raytrace.comp:562-564), so where one frame of the tile leaves the GPU short of pixels — a 1/8-height tile of a 1080p frame
- * has fewer pixels than the GPU has resident lanes, and a pixel's samples are serial — their pixels share one launch and
- * the frames are blended into d_rgba in order afterwards. Not for the debug heat maps (rendered frame by frame then).
- * "frames_per_launch" (rt_set_tuning) caps the frames per launch; 0 = as many as fit. */
+ * raytrace.comp:562-564), and a pixel's samples are serial, so what fills a GPU is paths: the frames' paths share one dispatch
+ * (one launch of the fused kernel, or the queues of every round of the multi-kernel pipeline; the pipeline is chosen by the
+ * paths of all the frames together) and the frames are blended into d_rgba in order afterwards. A 1/8-height tile of a
+ * 1080p frame has fewer pixels than the GPU has resident lanes; eight frames of it run like a whole frame, and the
+ * traversal gets cheaper per ray the more paths a dispatch holds. Not for the debug heat maps (rendered frame by frame then).
+ * "frames_per_launch" (rt_set_tuning) caps the frames per dispatch (0 = as many as fit), "frames_max_mslots" the paths of
+ * one dispatch in millions (default 24: 5.8 GB of path state); more frames than that go in several dispatches. */
 int  rt_render_frames(rt_ctx* ctx, const PushConstants* pc, uint32_t width, uint32_t height,
                       uint32_t row0, uint32_t rowStride, uint32_t nRows, uint32_t nFrames, float* d_rgba);
 int  rt_sync(rt_ctx* ctx);
@@ -339,11 +342,11 @@ int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
  *   "pipeline"       -1 (default) pick by tile size, 0 = multi-kernel wavefront pipeline
  *                    (k_trace_pw + k_shade per round), 1 = wave-private fused pipeline
  *                    (k_render_fused: every wave runs the stages on its own 8x8 pixel blocks)
- *   "fused_below_pixels"  tile size below which -1 picks the fused pipeline
+ *   "fused_below_pixels"  paths of a dispatch (tile pixels x frames) below which -1 picks the fused pipeline
  *   "fused_below_box_tests"  ... and box tests per ray (measured on the context's earlier dispatches of
  *                    the scene, copied back without waiting) below which it does so at any size
  *   "trace_variant"  0 = one ray per lane (k_trace), 1 = persistent waves (k_trace_pw)
- *   "refill", "chunk", "w_setup", "w_leaf", "fast_lanes", "lds_stack", "blocks_per_cu",
+ *   "refill", "mk_refill", "chunk", "w_setup", "w_leaf", "fast_lanes", "lds_stack", "blocks_per_cu",
  *   "tile_slots", "phase_stats": traversal scheduling details, see DESIGN.md
  *   "fast_share"     sixteenths of the lanes that hold a ray which suffice to skip the vote (with "fast_lanes" as the
  *                    upper limit; 0 = "fast_lanes" only)
