@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--tune", default="", help="comma-separated rt_set_tuning knobs, e.g. blocks_per_cu=2,refill=8")
     ap.add_argument("--force-collective", action="store_true",
                     help="send a one-rank job through the process group, gather and reductions too (RCCL smoke test on a one-GPU box)")
+    ap.add_argument("--no-in-flight-check", action="store_true", help="one GPU: skip re-rendering all steps one dispatch at a time for the comparison with the timed image")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the whole frame alone and compares it with the gathered one")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="most steps (= progressive frames) a rank submits at once through rt_render_frames; 0 = 10 N on N GPUs. A pixel's "
@@ -257,6 +258,18 @@ def main():
             out["parity_check"] = {"rows": tile["nRows"], "pixels": int(tile["nRows"] * W), "spp": args.spp, "equal": same,
                                    "max_rel": max_rel, "pipelines": ["multi-kernel", "fused"],
                                    "against": "oracle (scalar restatement of raytrace.comp), same rows, frameCount 0"}
+        if world == 1 and not multi and not args.no_in_flight_check:
+            # the frame the timed groups left behind (warm-up + steps, several steps per dispatch) against the same steps
+            # dispatched one by one: bit for bit, or the run fails
+            r.reset_counters()
+            solo = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
+            for i in range(args.warmup + args.steps):
+                pc.frameCount = i
+                r.render(pc, W, H, out_ptr=solo.data_ptr(), sync=True)
+            same = bool(torch.equal(solo.view(torch.int32), strip.view(torch.int32)))
+            out["in_flight_check"] = {"equal": same, "frames": args.warmup + args.steps,
+                                      "what": "the progressive image after all steps, rendered in groups (steps in flight), equals the one rendered one dispatch per step"}
+            del solo
         if args.check and multi:
             # the same frames rendered by one process must equal the stitched strips bit for bit
             r.reset_counters()
@@ -271,6 +284,8 @@ def main():
         print(json.dumps(out), flush=True)
         if out.get("parity_check", {}).get("equal") is False:
             raise SystemExit("parity_check failed: the GPU rows differ from the oracle's")
+        if out.get("in_flight_check", {}).get("equal") is False:
+            raise SystemExit("in_flight_check failed: the image rendered with several steps in flight differs from the one rendered step by step")
     if multi:
         dist.barrier()
         dist.destroy_process_group()

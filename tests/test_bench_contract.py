@@ -28,6 +28,7 @@ def test_bench_line_has_the_contract_fields():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
     p = d["parity_check"]
     assert p["equal"] is True and p["max_rel"] == 0.0 and p["rows"] >= 4
+    assert d["in_flight_check"]["equal"] is True and d["in_flight_check"]["frames"] == 3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
 

@@ -9,7 +9,7 @@ mkdir -p $out
 CMD="python3 bench.py --steps 10 --warmup 10 --spp 8 --tune probe=0 $*"   # one warm-up group and one timed group of ten steps in flight (what the default bench.py run does twice); no ray-cost probe (its small launches would sit in the per-kernel averages; the warm-up measures the ray cost instead)
 timeout -k 10 400 $CMD > $out/bench.log 2>&1 || { tail -5 $out/bench.log; exit 1; }
 grep '^{' $out/bench.log | tail -1 > $out/bench.json
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD --cpu-seconds 0 > $out/bench_under_rocprof.log 2>&1 || { tail -5 $out/bench_under_rocprof.log; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD --cpu-seconds 0 --no-in-flight-check > $out/bench_under_rocprof.log 2>&1 || { tail -5 $out/bench_under_rocprof.log; exit 1; }
 grep '^{' $out/bench_under_rocprof.log | tail -1 > $out/bench_under_rocprof.json
 cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
 kern=$(python3 -c "import json; print('k_render_fused' if 'fused' in json.load(open('$out/bench.json'))['config']['pipeline'] else 'k_trace_pw')")
@@ -17,7 +17,7 @@ kern=$(python3 -c "import json; print('k_render_fused' if 'fused' in json.load(o
 i=0
 for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_FLAT_READ_WAVEFRONTS_sum"; do
   i=$((i+1))
-  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc/pass_$i -- $CMD --cpu-seconds 0 > $out/pmc_$i.log 2>&1 || { echo "pmc pass $i ($set) failed"; tail -5 $out/pmc_$i.log; }
+  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc/pass_$i -- $CMD --cpu-seconds 0 --no-in-flight-check > $out/pmc_$i.log 2>&1 || { echo "pmc pass $i ($set) failed"; tail -5 $out/pmc_$i.log; }
   [ $i = 1 ] && grep '^{' $out/pmc_$i.log | tail -1 > $out/pmc/bench_pass.json
 done
 python3 tools/pmc_roofline.py $out/pmc $kern $out/counters_$kern.json "$CMD (PMC passes: --cpu-seconds 0)" > $out/pmc_roofline.log 2>&1 || tail -5 $out/pmc_roofline.log
