@@ -304,20 +304,25 @@ class Renderer:
         self.sync()
         return None if out_ptr else self.read_rgba()
 
-    def run_compute(self, pc, width, height, **tile):
+    def run_compute(self, pc, width, height, frames=1, **tile):
         """Frame semantics of draw()/run_compute (src/vk_engine.cpp:1782,1812-1814); `tile` = row0 / rowStride / nRows
-        of rt_render when the frame is split over several GPUs."""
+        of rt_render when the frame is split over several GPUs. `frames` > 1 (progressive accumulation only): that many of
+        the frames the loop would dispatch one after the other go in one rt_render_frames call — the same image, sooner."""
         t = pc.rayTraceParams
         if self.totalSamples >= t.sampleLimit:
             return None
         pc.frameCount = self._frameNumber
-        img = self.render(pc, width, height, **tile)
+        n = 1
+        if frames > 1 and t.progressive and not t.singleRender and t.raysPerPixel > 0:
+            left = (t.sampleLimit - self.totalSamples + t.raysPerPixel - 1) // t.raysPerPixel
+            n = max(1, min(int(frames), int(left)))
+        img = self.render(pc, width, height, **tile) if n == 1 else self.render_frames(pc, width, height, n, **tile)
         if t.singleRender:
             self.totalSamples = t.sampleLimit
         else:
-            self.totalSamples += t.raysPerPixel
+            self.totalSamples += t.raysPerPixel * n
         if t.progressive:
-            self._frameNumber += 1
+            self._frameNumber += n
         return img
 
     def sync(self):

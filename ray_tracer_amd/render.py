@@ -58,6 +58,9 @@ def build_parser():
     ap.add_argument("--out", help="PNG (8-bit sRGB) or .npy (fp32 RGBA) output file")
     # Ray Tracer Info panel
     ap.add_argument("--progressive", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="progressive accumulation: frames handed to the GPU at once (rt_render_frames: the same image as one "
+                         "dispatch per frame, sooner — more paths per dispatch; 1 = the reference's frame loop)")
     ap.add_argument("--single-render", action="store_true")
     ap.add_argument("--debug", type=int, default=-1, choices=[-1, 0, 1, 2])
     ap.add_argument("--rays-per-pixel", type=int, default=1)
@@ -156,7 +159,7 @@ def main(argv=None):
     frames = 0
     img = None
     while True:
-        out = r.run_compute(pc, W, H, **tile)
+        out = r.run_compute(pc, W, H, frames=args.frames_in_flight, **tile)
         if out is None:
             break
         img = out

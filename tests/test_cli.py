@@ -42,6 +42,17 @@ def test_cli_renders_cornell(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_frames_in_flight_write_the_same_frame(tmp_path):
+    """--frames-in-flight: the progressive loop hands several frames to rt_render_frames at once (7 frames as 3 + 3 + 1):
+    the same fp32 frame, bit for bit, as the reference's one dispatch per frame."""
+    job = "--scene bunny --width 96 --height 64 --progressive --rays-per-pixel 2 --sample-limit 14"
+    one, many = tmp_path / "one.npy", tmp_path / "many.npy"
+    assert render.main(f"{job} --out {one}".split()) == 0
+    assert render.main(f"{job} --frames-in-flight 3 --out {many}".split()) == 0
+    assert np.array_equal(np.load(one).view(np.uint32), np.load(many).view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_cli_on_two_ranks_writes_the_single_process_frame(tmp_path):
     """python -m torch.distributed.run ... -m ray_tracer_amd.render: two ranks (gloo, both on this box's one GPU) render
     the interleaved rows of a progressive three-dispatch job, rank 0 stitches and writes: the same fp32 frame, bit for
