@@ -177,7 +177,7 @@ int ensure_state(rt_ctx* c, uint32_t nPixels) {
     if (c->capacity >= nPixels && c->stateBuf.p) return 0;
     const size_t stride4 = (((size_t)nPixels * 16) + 255) & ~(size_t)255;  // bytes per float4 array
     const size_t stride1 = (((size_t)nPixels * 4) + 255) & ~(size_t)255;
-    const int nF4 = 15, nU1 = 2;
+    const int nF4 = 14, nU1 = 2;
     int rc = dev_alloc(c, c->stateBuf, stride4 * nF4 + stride1 * nU1);
     if (rc) return rc;
     PathState& ps = c->ps;
@@ -1016,11 +1016,11 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
         c->pixStats = false;
     }
     const bool shortRays = c->boxPerRay >= 0.0 && c->boxPerRay < (double)c->fusedBelowBoxTests;
-    // the longer the rays, the earlier the global queue of the multi-kernel pipeline pays: Sponza (157 box tests per ray)
-    // switches near 6 M pixels (1440p: fused 315 ms per 8 spp against 329; 4K: 700 against 686), Sponza + 16 dragons (213)
-    // near 2 M (1/8 of a 4K frame: 85 against 94; 1/4: 162 against 159)
+    // the longer the rays, the earlier the global queue of the multi-kernel pipeline pays: Sponza (153 box tests per ray)
+    // switches near 4 M paths (two 1080p frames: 113.5 ms per step either way; four: 103.9 against 111.3), Sponza + 16
+    // dragons (213) near 2 M (one 1080p frame: fused 187 ms per 8 spp against 195; a 4K frame: 369 against 299)
     double sizeLimit = (double)c->fusedBelowPixels;
-    if (c->boxPerRay > 160.0) sizeLimit = std::max(800000.0, sizeLimit - (c->boxPerRay - 160.0) * 75000.0);
+    if (c->boxPerRay > 160.0) sizeLimit = std::max(0.5 * sizeLimit, sizeLimit - (c->boxPerRay - 160.0) * 38000.0);
     // (the paths of all the frames of the dispatch count: four frames of a quarter of a 4K frame are a 4K frame's worth)
     c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (((double)nSlots < sizeLimit || shortRays) ? 1 : 0);
     if (c->lastPipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch

@@ -116,15 +116,16 @@ struct PathState {
     __host__ __device__ __forceinline__ float4* auxDL() const { return arr(3); }       // NEE direction              | w: cosineHemispherePDF(n, lightSample)  (:448)
     __host__ __device__ __forceinline__ float4* auxDC() const { return arr(4); }       // cosine-sample direction    | w: cosineHemispherePDF(n, cosineSample) (:454)
     __host__ __device__ __forceinline__ float4* hit(uint32_t kind) const { return arr(5 + kind); }  // per ray kind. From the ray's creator: {closest sphere hit, its object bits, object mask, tE of a light query or 0}; from the traversal: {dst, object bits, triangle bits, 0}
-    __host__ __device__ __forceinline__ float4* att() const { return arr(8); }         // attenuation                | w: bounce index j, bit 31 = NEE results pending
+    __host__ __device__ __forceinline__ float4* att() const { return arr(8); }         // attenuation                | w: bounce index j, bit 31 = NEE results pending, bit 30 = the last bounce was specular (directLight = -1, :469,480)
     __host__ __device__ __forceinline__ float4* total() const { return arr(9); }       // totalColor                 | w: samples finished for this pixel
-    __host__ __device__ __forceinline__ float4* direct() const { return arr(10); }     // directLight
-    __host__ __device__ __forceinline__ float4* pendAlbedo() const { return arr(11); } // albedo of the previous diffuse hit
-    __host__ __device__ __forceinline__ float4* accum() const { return arr(12); }      // sum of trace() over the pixel's samples (:572)
-    __host__ __device__ __forceinline__ float4* camHit() const { return arr(13); }     // the camera ray's hit record, kept from the pixel's first sample (FrameParams::camReuse)
-    __host__ __device__ __forceinline__ float4* camDir() const { return arr(14); }     // the camera ray's direction (every sample of the pixel starts with it: no jitter, raytrace.comp:541-557)
-    __host__ __device__ __forceinline__ uint32_t* statBox() const { return (uint32_t*)arr(15); }             // stats[0] of the pixel (main-path traversals only)
-    __host__ __device__ __forceinline__ uint32_t* statTri() const { return (uint32_t*)arr(15) + pitchStat; } // stats[1]
+    // (directLight has no record: between two segments it is either about to be recomputed from the probe results — bit 31 of
+    // att.w — or one of two constants: -1 after a specular bounce, bit 30, and 0 at the start of a sample)
+    __host__ __device__ __forceinline__ float4* pendAlbedo() const { return arr(10); } // albedo of the previous diffuse hit
+    __host__ __device__ __forceinline__ float4* accum() const { return arr(11); }      // sum of trace() over the pixel's samples (:572)
+    __host__ __device__ __forceinline__ float4* camHit() const { return arr(12); }     // the camera ray's hit record, kept from the pixel's first sample (FrameParams::camReuse)
+    __host__ __device__ __forceinline__ float4* camDir() const { return arr(13); }     // the camera ray's direction (every sample of the pixel starts with it: no jitter, raytrace.comp:541-557)
+    __host__ __device__ __forceinline__ uint32_t* statBox() const { return (uint32_t*)arr(14); }             // stats[0] of the pixel (main-path traversals only)
+    __host__ __device__ __forceinline__ uint32_t* statTri() const { return (uint32_t*)arr(14) + pitchStat; } // stats[1]
 };
 
 struct Queues {
@@ -1131,7 +1132,6 @@ __device__ __forceinline__ void init_path(const DevScene& sc, const PathState& p
     ps.hit(RAY_MAIN)[slot] = sphere_seed(sc, rt_v3(fp.camPos[0], fp.camPos[1], fp.camPos[2]), pd);
     ps.att()[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(0u));                                   // j = 0
     ps.total()[slot] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));                                 // sample 0
-    ps.direct()[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     ps.accum()[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
     ps.statBox()[slot] = 0;
     ps.statTri()[slot] = 0;
@@ -1175,16 +1175,20 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
     bool wantAux = false;  // a diffuse bounce whose MIS the next segment finishes (raytrace.comp:443-460)
     auxMask = 0;
     rt_vec3 auxOrigin = rt_v3(0, 0, 0), auxL = auxOrigin, auxC = auxOrigin;  // probe rays of this bounce (diffuse only)
-    const float4 sO = ps.rayO()[slot], sD = ps.rayD()[slot], sA = ps.att()[slot], sT = ps.total()[slot], sDi = ps.direct()[slot];
+    const float4 sO = ps.rayO()[slot], sD = ps.rayD()[slot], sA = ps.att()[slot], sT = ps.total()[slot];
     const float4 hM = ps.hit(RAY_MAIN)[slot];
     rt_vec3 ro = f4xyz(sO), rd = f4xyz(sD);
-    rt_vec3 att = f4xyz(sA), total = f4xyz(sT), direct = f4xyz(sDi);
+    rt_vec3 att = f4xyz(sA), total = f4xyz(sT);
     float misW = sO.w;
     uint32_t state = __float_as_uint(sD.w);
     uint32_t jraw = __float_as_uint(sA.w);
     uint32_t samplesDone = __float_as_uint(sT.w);
-    uint32_t j = jraw & 0x7fffffffu;
+    uint32_t j = jraw & 0x3fffffffu;
     const bool pending = (jraw >> 31) != 0u;
+    // directLight as the last segment left it (raytrace.comp:487,469,480,460): -1 after a specular bounce, 0 at the start of a
+    // sample; after a diffuse bounce the block below recomputes it before it is read
+    rt_vec3 direct = (jraw & 0x40000000u) ? rt_v3(-1.f, -1.f, -1.f) : rt_v3(0.f, 0.f, 0.f);
+    bool specular = false;  // this segment's bounce is a mirror or dielectric one
 
     const uint32_t obj = __float_as_uint(hM.y);
     const uint32_t hitTriIdx = __float_as_uint(hM.z);
@@ -1242,7 +1246,7 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
             if (mA.w != 0.f) {  // reflectance != 0: mirror (:466-469)
                 sampledDir = rt_reflect(rd, hit.normal);
                 radiance = rt_v3(1.f, 1.f, 1.f);
-                direct = rt_v3(-1.f, -1.f, -1.f);
+                specular = true;   // directLight = -1 (:469)
                 misW = 1.f;
             } else if (mI.x != -1.f) {  // dielectric (:471-481)
                 float ior = !hit.frontFace ? mI.x : 1.f / mI.x;
@@ -1253,7 +1257,7 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
                 sampledDir = solution ? rt_reflect(rd, hit.normal) : rt_refract(rd, hit.normal, ior);
                 originSign = solution ? 1.f : rt_sign(rt_dot(hit.normal, rd));
                 radiance = rt_v3(1.f, 1.f, 1.f);
-                direct = rt_v3(-1.f, -1.f, -1.f);
+                specular = true;   // directLight = -1 (:480)
                 misW = 1.f;
             } else {  // diffuse + NEE/MIS (:430-464), first half
                 diffuse = true;
@@ -1330,7 +1334,7 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
             rd = f4xyz(ps.camDir()[slot]);
             att = rt_v3(1.f, 1.f, 1.f);
             total = rt_v3(0.f, 0.f, 0.f);
-            direct = rt_v3(0.f, 0.f, 0.f);
+            specular = false;  // directLight = 0 (:487)
             misW = 1.f;
             j = 0;
             alive = true;
@@ -1368,9 +1372,8 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
         }
         ps.rayO()[slot] = mk4(ro, misW);
         ps.rayD()[slot] = mk4u(rd, state);
-        ps.att()[slot] = mk4u(att, j | (wantAux ? 0x80000000u : 0u));
+        ps.att()[slot] = mk4u(att, j | (wantAux ? 0x80000000u : 0u) | (specular ? 0x40000000u : 0u));
         ps.total()[slot] = mk4u(total, samplesDone);
-        ps.direct()[slot] = mk4(direct, 0.f);
     }
 }
 
