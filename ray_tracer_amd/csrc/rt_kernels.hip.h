@@ -659,7 +659,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
         if (obj < sc.objectCount) {
             // {root word, flags} of the next object: from the work-group's LDS copy (metaLds: the first RT_META_LDS objects) — one
             // vector load per object and ray less on the memory pipeline that bounds the traversal (Sponza: 26 of ~400 per ray)
-            if (!CULL && obj < RT_META_LDS) {   // (not in the CULL instantiations: see the note at fill_meta_lds)
+            if (obj < RT_META_LDS) {
                 const uint2 m = metaLds[obj];
                 nxW = m.x; fl = m.y;
             } else {
@@ -924,15 +924,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
 
 }
 
-// the work-group's LDS copy of the first RT_META_LDS objects' {root word, flags} (fetch_next_meta). Scenes of identity-transform
-// objects only (the CULL = false instantiations: Sponza and the flattened C5, where a ray walks through every object's root):
-// with it the instantiation k_render_fused<24, false, false, true> rendered wrong frames (Cornell + bunny stand-in, klein
-// bottle: thousands of pixels, fewer rays traced) while k_trace_pw with the same trace_wave and every other fused instantiation
-// stayed bit-identical to the oracle — the second time that very instantiation (69 spilled SGPRs) came out wrong after an edit
-// that is right in the source (profiles/README.md); the scenes it serves have ten objects, so nothing is lost by leaving it out.
-template <bool CULL>
+// the work-group's LDS copy of the first RT_META_LDS objects' {root word, flags} (fetch_next_meta)
 __device__ __forceinline__ void fill_meta_lds(const DevScene& sc, uint2* s_meta) {
-    if (CULL) return;
     if (threadIdx.x < RT_META_LDS) {
         uint2 m = make_uint2(0u, 0u);
         if (threadIdx.x < sc.objectCount) { const uint4 q = sc.objMeta[threadIdx.x]; m = make_uint2(q.x, q.w & 0xffu); }
@@ -944,8 +937,8 @@ __device__ __forceinline__ void fill_meta_lds(const DevScene& sc, uint2* s_meta)
 template <int STACK, bool OVF, bool PIX, bool STATS, bool CULL>
 __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];  // +1: pushes are unconditional
-    __shared__ uint2 s_meta[CULL ? 1 : RT_META_LDS];
-    fill_meta_lds<CULL>(sc, s_meta);
+    __shared__ uint2 s_meta[RT_META_LDS];
+    fill_meta_lds(sc, s_meta);
     uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
     // overflow entries of this lane: index k at ovf[k * ovfStride]
     uint32_t* ovf = OVF ? ta.overflow + (size_t)blockIdx.x * RT_BLOCK + threadIdx.x : nullptr;
@@ -1525,13 +1518,8 @@ struct FusedKernArgs {  // the whole kernel-argument segment, so that it can be 
     FusedArgs fa;
 };
 
-// PIX (the heat maps' per-ray counters, two more registers through the traversal loop) is built for four blocks per CU:
-// at five the instantiation <24, false, true, true> spilled 110 VGPRs / 60 SGPRs and its per-ray counts came out wrong on a
-// pixel's second and later samples (klein bottle + Cornell, debug 2: 28 box tests short of 1.7 M) while its rays, hits and
-// radiance stayed bit-identical — the same source built for four blocks (no spills to speak of) counts right, as do all the
-// other instantiations; profiles/README.md, "r02 a miscounting heat-map instantiation". Heat maps are a debug view; speed is not the point there.
 template <int STACK, bool OVF, bool PIX, bool CULL>
-__global__ __launch_bounds__(RT_BLOCK, PIX ? 4 : 5) void k_render_fused(FusedKernArgs ka) {
+__global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) {
     const DevScene& sc = ka.sc;
     const PathState& ps = ka.ps;
     const FrameParams& fp = ka.fp;
@@ -1539,11 +1527,10 @@ __global__ __launch_bounds__(RT_BLOCK, PIX ? 4 : 5) void k_render_fused(FusedKer
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];
     __shared__ uint32_t s_list[RT_BLOCK / RT_WAVE][3 * RT_WAVE];
     __shared__ float4 s_box[64];  // DevScene::maskBox (the objects of the mask's window that can be ruled out): the rays' object masks are computed from here (reach_mask_from)
-    __shared__ uint2 s_meta[CULL ? 1 : RT_META_LDS];
+    __shared__ uint2 s_meta[RT_META_LDS];
     const uint32_t nBox = CULL ? sc.reachCount : 0u;
     if (CULL && threadIdx.x < 2u * nBox) s_box[threadIdx.x] = sc.maskBox[threadIdx.x];
-    fill_meta_lds<CULL>(sc, s_meta);
-    if (CULL) __syncthreads();
+    fill_meta_lds(sc, s_meta);
     const uint32_t wv = threadIdx.x / RT_WAVE;
     uint32_t* stack = s_stack + wv * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
     uint32_t* list = s_list[wv];
