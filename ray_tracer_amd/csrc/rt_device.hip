@@ -109,6 +109,8 @@ struct rt_ctx {
     int maskIdentity = 0;   // identity-transform objects in the rays' object masks too (rt_update_objects reads it)
     int scatter = -1;       // fused pipeline: blocks made of chunks of this many slots from all over the tile; 0 = neighbouring pixels; -1 = auto
     uint64_t framesMaxSlots = RT_FRAMES_MAX_SLOTS;  // most paths of one multi-frame dispatch (rt_render_frames)
+    int hotPairs = 2;       // k_trace_pw: child pairs of the meshes' top levels from LDS. 0 = off, 1 = as many as fit beside the stacks of
+                            // six work-groups per CU, 2 = of five (Sponza, 21-entry stacks, ten frames in flight: 90.4 / 90.6 / 88.7 ms per step)
     int pixelRefill = 0;    // fused pipeline: free lanes at which a wave reserves new pixels (64 = a block at a time, 0 = by ray length)
     int batchPixels = 0;    // fused pipeline: pixels per wave-private block (0 = chosen per launch)
     int batchFixed = 80;    // ... and the fixed part of a block's cost in the chooser, in pixel units
@@ -202,9 +204,22 @@ int ensure_state(rt_ctx* c, uint32_t nPixels) {
 
 template <int STACK, bool OVF, bool CULL>
 int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
+    // per-ray counters are only needed for the pixel heat maps (debug >= 0) and rt_trace_rays
+    const bool pix = c->pixStats || ta.perRayBox;
+    // top-level pairs from LDS (k_trace_pw<HOT>): what 160 KB of LDS per CU leave beside the stacks. hot_pairs 1: six work-groups
+    // per CU, 2: five (more pairs, no spills at 96 registers)
+    constexpr int HOT6 = OVF ? 0 : STACK == 8 ? 192 : STACK == 16 ? 136 : STACK == 20 ? 72 : 0;
+    constexpr int HOT5 = OVF ? 0 : STACK == 24 ? 80 : STACK == 20 ? 144 : 192;
+    int hotMode = (!pix && !c->phaseStats && c->sc.hotNodes > 0) ? c->hotPairs : 0;
+    if (hotMode == 1 && HOT6 == 0) hotMode = 2;   // (a 24-entry stack leaves no room at six work-groups)
+    if (hotMode == 2 && HOT5 == 0) hotMode = 0;   // (overflow-stack instantiations: not built with the table)
     int perCU = c->blocksPerCU;
     if (perCU <= 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false, CULL>, RT_BLOCK, 0) != hipSuccess || perCU <= 0) perCU = 4;
+        hipError_t e;
+        if (hotMode == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false, CULL, HOT6, 6>, RT_BLOCK, 0);
+        else if (hotMode == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false, CULL, HOT5, 5>, RT_BLOCK, 0);
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false, CULL>, RT_BLOCK, 0);
+        if (e != hipSuccess || perCU <= 0) perCU = 4;
     }
     uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
     uint32_t blocks = std::min((maxRays + RT_BLOCK - 1) / RT_BLOCK, resident);
@@ -224,9 +239,9 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     }
     TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refillMk, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, (uint32_t)c->fastShare,
                    ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), waveTimes, overflow};
-    // per-ray counters are only needed for the pixel heat maps (debug >= 0) and rt_trace_rays
-    const bool pix = c->pixStats || ta.perRayBox;
-    if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, true, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    if (hotMode == 1) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL, HOT6, 6>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    else if (hotMode == 2) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL, HOT5, 5>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    else if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, true, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
     else if (pix) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, false, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
     else hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
     return 0;
@@ -376,6 +391,7 @@ int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
             else if (cap < 16) rc = launch_pw_t<8, true, true>(c, maxRays, ta);
             else if (d <= 16) rc = launch_pw_t<16, false, true>(c, maxRays, ta);
             else if (cap < 24) rc = launch_pw_t<16, true, true>(c, maxRays, ta);
+            else if (d <= 20) rc = launch_pw_t<20, false, true>(c, maxRays, ta);
             else if (d <= 24) rc = launch_pw_t<24, false, true>(c, maxRays, ta);
             else rc = launch_pw_t<24, true, true>(c, maxRays, ta);
         }
@@ -383,6 +399,7 @@ int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
         else if (cap < 16) rc = launch_pw_t<8, true, false>(c, maxRays, ta);
         else if (d <= 16) rc = launch_pw_t<16, false, false>(c, maxRays, ta);
         else if (cap < 24) rc = launch_pw_t<16, true, false>(c, maxRays, ta);
+        else if (d <= 20) rc = launch_pw_t<20, false, false>(c, maxRays, ta);
         else if (d <= 24) rc = launch_pw_t<24, false, false>(c, maxRays, ta);
         else rc = launch_pw_t<24, true, false>(c, maxRays, ta);
     }
@@ -730,18 +747,40 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
 
     // ---- device node numbering: shift each mesh so its child pairs (which
     // follow the root in twos) start on an even index = 64-byte boundary
-    c->nodeRemap.assign(nNodes, 0);
-    uint32_t shift = 0, devCount = 0;
+    // The child pairs of the top levels of every mesh come first (breadth first over all roots, level by level, at most
+    // RT_HOT_PAIRS of them): k_trace_pw<HOT> keeps exactly those in LDS (DevScene::hotNodes).
+    c->nodeRemap.assign(nNodes, 0xffffffffu);
+    uint32_t devCount = 0;
     {
+        std::vector<uint32_t> level, next;
+        for (uint32_t root : roots) level.push_back(root);
+        uint32_t hot = 0;
+        for (int depth = 0; depth < 8 && !level.empty() && hot < RT_HOT_PAIRS; depth++) {
+            next.clear();
+            for (uint32_t nidx : level) {
+                const BVHNode& b = s->bvhNodes[nidx];
+                if (b.triCount != 0 || hot >= RT_HOT_PAIRS) continue;
+                if (b.index + 1 >= nNodes) return c->fail("BVH child index out of range");
+                if (c->nodeRemap[b.index] != 0xffffffffu) continue;  // (a malformed BVH that shares children)
+                c->nodeRemap[b.index] = 2 * hot;
+                c->nodeRemap[b.index + 1] = 2 * hot + 1;
+                hot++;
+                next.push_back(b.index);
+                next.push_back(b.index + 1);
+            }
+            level.swap(next);
+        }
+        c->sc.hotNodes = 2 * hot;
+        uint32_t pos = 2 * hot;
         size_t r = 0;
         for (uint32_t nidx = 0; nidx < nNodes; nidx++) {
-            if (r < roots.size() && roots[r] == nidx) {
-                if (((nidx + shift) & 1u) == 0u) shift++;  // root on an odd slot
-                r++;
-            }
-            c->nodeRemap[nidx] = nidx + shift;
+            const bool isRoot = r < roots.size() && roots[r] == nidx;
+            if (isRoot) r++;
+            if (c->nodeRemap[nidx] != 0xffffffffu) continue;  // a hot pair's node
+            if (isRoot && (pos & 1u) == 0u) pos++;             // root on an odd slot: the pairs that follow it in twos start even
+            c->nodeRemap[nidx] = pos++;
         }
-        devCount = nNodes + shift;
+        devCount = pos;
     }
 
     std::vector<float4> nodes((size_t)std::max(devCount, 2u) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -1262,6 +1301,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "fused_below_pixels") { if (value < 0) return c->fail("fused_below_pixels >= 0"); c->fusedBelowPixels = (uint32_t)value; }
     else if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
     else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; c->refillMk = value; }
+    else if (k == "hot_pairs") { if (value < 0 || value > 2) return c->fail("hot_pairs: 0, 1 (six work-groups per CU) or 2 (five)"); c->hotPairs = value; }
     else if (k == "mk_refill") { if (value < 1 || value > 64) return c->fail("mk_refill: 1..64"); c->refillMk = value; }
     else if (k == "lds_stack") { if (value != 8 && value != 16 && value != 24) return c->fail("lds_stack: 8, 16 or 24"); c->ldsStackCap = value; }
     else if (k == "fast_lanes") { if (value < 0 || value > 65) return c->fail("fast_lanes: 1..65 (0: back to the defaults)"); c->fastLanesSet = value != 0; c->fastLanes = value ? value : 32; }

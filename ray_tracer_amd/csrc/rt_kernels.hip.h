@@ -67,6 +67,9 @@ struct DevScene {
     const float4* spheres;
     const uint32_t* sphereMat;
     uint32_t sphereCount, objectCount, materialCount, nodeCount, triCount;
+    uint32_t hotNodes;        // the device numbering puts the child pairs of the top levels of every mesh first (breadth first over all
+                              // roots): node indices below this (an even number, at most 2 * RT_HOT_PAIRS) are the pairs a work-group of
+                              // k_trace_pw<HOT> keeps in LDS
     uint32_t sphereTestMask;  // spheres sphere_seed has to test: all but those whose {center, radius} repeat an earlier sphere's bit for
                               // bit (the reference always uploads MAX_SPHERES = 10, src/vk_engine.cpp:682-686, zeroed when unused).
                               // A repeat computes the earlier sphere's very result and can never win the loop's strict `dst < best`
@@ -568,6 +571,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
 //     zero, negative-zero or non-finite; other rays take the general path).
 //     The next object's metadata is fetched one object ahead.
 #define RT_META_LDS 128u           // objects whose {root word, flags} a work-group keeps in LDS (1 KB)
+#define RT_HOT_PAIRS 192u          // child pairs of the meshes' top levels that come first in the device numbering; k_trace_pw<HOT> keeps the first HOT of them in LDS
 #define RT_CUR_IDLE 0xffffffffu   // no ray
 #define RT_CUR_NEED 0xfffffffeu   // wants its next node (tail)
 #define RT_CUR_SETUP 0xfffffffdu  // entering object `obj`, which has a general transform
@@ -615,9 +619,10 @@ struct WaveTotals {
 // goes straight to the interior step; pushes and pops are unconditional LDS accesses with
 // predicated pointer updates; the full vote, the refill and the leaf / setup steps live on a slow
 // path that is only entered when fewer than `fastLanes` lanes are at interior nodes.
-template <int STACK, bool OVF, bool PIX, bool STATS, bool LOCAL, bool CULL>
+template <int STACK, bool OVF, bool PIX, bool STATS, bool LOCAL, bool CULL, int HOT = 0>
 __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& ps, const TracePwArgs& ta, uint32_t* stack, uint32_t* ovf,
-                                           size_t ovfStride, const uint32_t* localList, uint32_t n, WaveTotals& wt, const uint2* metaLds) {
+                                           size_t ovfStride, const uint32_t* localList, uint32_t n, WaveTotals& wt, const uint2* metaLds,
+                                           const float4* hotLds = nullptr) {
     uint32_t cur = RT_CUR_IDLE;
     uint32_t id = 0, qidx = 0;
     // ray in the current object's space and 1/dir (written by the setup step only); x and y are kept as
@@ -865,9 +870,18 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                 wt.dbgWait[2] += __popcll(__ballot(cur == RT_CUR_IDLE));
             }
             if ((int32_t)cur >= 0) {
-                const float4* pr = sc.nodesPk + 2 * (size_t)cur;
-                const float4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
-                const float2 lk = *(const float2*)(pr + 3);
+                float4 q0, q1, q2;
+                float2 lk;
+                if (HOT && cur < min(sc.hotNodes, 2u * (uint32_t)HOT)) {
+                    // a child pair of a mesh's top levels: from the work-group's LDS copy, not through the vector memory pipeline
+                    const float4* ph = hotLds + 2 * cur;
+                    q0 = ph[0]; q1 = ph[1]; q2 = ph[2];
+                    lk = *(const float2*)(ph + 3);
+                } else {
+                    const float4* pr = sc.nodesPk + 2 * (size_t)cur;
+                    q0 = pr[0]; q1 = pr[1]; q2 = pr[2];
+                    lk = *(const float2*)(pr + 3);
+                }
                 float d1, d2;
                 box_intersect_pair(q0, q1, q2, troXY, invXY, zOI, d1, d2);
                 if (PIX) rayBox += 2; else wt.totBox += 2;
@@ -934,10 +948,14 @@ __device__ __forceinline__ void fill_meta_lds(const DevScene& sc, uint2* s_meta)
     __syncthreads();
 }
 
-template <int STACK, bool OVF, bool PIX, bool STATS, bool CULL>
-__global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
+// HOT > 0: the first HOT child pairs of the device numbering (the meshes' top levels, DevScene::hotNodes) are served from a copy
+// in LDS (64 B each); BLOCKS = work-groups per CU the kernel is built for (what the LDS of stack + table leaves room for)
+template <int STACK, bool OVF, bool PIX, bool STATS, bool CULL, int HOT = 0, int BLOCKS = 6>
+__global__ __launch_bounds__(RT_BLOCK, BLOCKS) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];  // +1: pushes are unconditional
     __shared__ uint2 s_meta[RT_META_LDS];
+    __shared__ float4 s_hot[HOT ? 4 * HOT : 1];
+    if (HOT) for (uint32_t k = threadIdx.x; k < 2u * min(sc.hotNodes, 2u * (uint32_t)HOT); k += RT_BLOCK) s_hot[k] = sc.nodesPk[k];
     fill_meta_lds(sc, s_meta);
     uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * (STACK + 1) * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
     // overflow entries of this lane: index k at ovf[k * ovfStride]
@@ -945,7 +963,7 @@ __global__ __launch_bounds__(RT_BLOCK, 6) void k_trace_pw(DevScene sc, PathState
     const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
     WaveTotals wt;
     const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
-    trace_wave<STACK, OVF, PIX, STATS, false, CULL>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt, s_meta);
+    trace_wave<STACK, OVF, PIX, STATS, false, CULL, HOT>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt, s_meta, s_hot);
 
     if (STATS && lane_id() == 0) {
         const size_t w = (size_t)blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;

@@ -269,11 +269,45 @@ def test_both_traversal_kernels_and_knobs_agree(renderer):
             img = renderer.render(pc, W, H)
             _check(img, renderer.counters(), ref, rc)
     finally:
-        for k, v in {"trace_variant": 1, "refill": 8, "fast_lanes": 24, "chunk": 256, "w_setup": 32, "w_leaf": 8,
+        for k, v in {"trace_variant": 1, "refill": 8, "mk_refill": 16, "fast_lanes": 24, "chunk": 256, "w_setup": 32, "w_leaf": 8,
                      "lds_stack": 24, "tile_slots": 1, "blocks_per_cu": 0}.items():
             renderer.set_tuning(k, v)
     with pytest.raises(engine.RtError):
         renderer.set_tuning("no_such_knob", 1)
+
+
+def test_top_level_pairs_from_lds(renderer):
+    """k_trace_pw<HOT>: the child pairs of the meshes' top levels come first in the device numbering and are served from a copy
+    in LDS — as many as fit beside the stacks of six work-groups per CU ("hot_pairs" 1), of five (2, the default), or not at
+    all (0). Scenes whose BVH depths select each stack size (8, 16, 20, 24 entries) and the overflow stack, which has no table."""
+    cases = [(cornell_scene(True), 64, 48),
+             (model_scene("bunny.obj", material=5, spheres=True), 96, 64),
+             (model_scene("klein_bottle.obj", material=4, scale=0.5, position=(0.0, -0.2, 0.0)), 96, 64)]
+    sp, _ = scenes.sponza(0, ntris=60000)
+    try:
+        renderer.set_tuning("pipeline", 0)
+        for s, W, H in cases:
+            pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2)
+            ref, rc = pyoracle.render(s, pc, W, H)
+            renderer.upload_scene(s)
+            for hot in (0, 1, 2):
+                renderer.set_tuning("hot_pairs", hot)
+                renderer.reset_counters()
+                _check(renderer.render(pc, W, H), renderer.counters(), ref, rc)
+        W, H = 1920, 1080
+        pc = scenes.sponza_camera(W, H, singleRender=1, sampleLimit=2)
+        tile = dict(row0=101, rowStride=135, nRows=8)
+        ref, rc = pyoracle.render(sp, pc, W, H, **tile)
+        renderer.upload_scene(sp)
+        for hot, cap in ((0, 24), (1, 24), (2, 24), (2, 8)):   # cap 8: the overflow stack, no table
+            renderer.set_tuning("hot_pairs", hot)
+            renderer.set_tuning("lds_stack", cap)
+            renderer.reset_counters()
+            _check(renderer.render(pc, W, H, **tile), renderer.counters(), ref, rc)
+    finally:
+        renderer.set_tuning("hot_pairs", 2)
+        renderer.set_tuning("lds_stack", 24)
+        renderer.set_tuning("pipeline", -1)
 
 
 def test_overflow_stack_beyond_the_lds_part(renderer):
