@@ -984,6 +984,7 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
     const RayTracerData& td = pc->rayTraceParams;
     if (td.sphereCount > c->sc.sphereCount) return c->fail("rayTraceParams.sphereCount exceeds the uploaded spheres");
     if (td.objectCount > c->sc.objectCount) return c->fail("rayTraceParams.objectCount exceeds the uploaded objects");
+    if (td.bounceLimit >= (1u << 28) - 1u) return c->fail("rayTraceParams.bounceLimit needs more than 28 bits");
     const uint64_t np64 = (uint64_t)nRows * width;
     if ((np64 + 63) / 64 * 64 * nFrames >= (1ull << 30)) return c->fail("tile too large (slot ids are 30 bits)");
     const uint32_t nPixels = (uint32_t)np64;

@@ -119,7 +119,7 @@ struct PathState {
     __host__ __device__ __forceinline__ float4* auxDL() const { return arr(3); }       // NEE direction              | w: cosineHemispherePDF(n, lightSample)  (:448)
     __host__ __device__ __forceinline__ float4* auxDC() const { return arr(4); }       // cosine-sample direction    | w: cosineHemispherePDF(n, cosineSample) (:454)
     __host__ __device__ __forceinline__ float4* hit(uint32_t kind) const { return arr(5 + kind); }  // per ray kind. From the ray's creator: {closest sphere hit, its object bits, object mask, tE of a light query or 0}; from the traversal: {dst, object bits, triangle bits, 0}
-    __host__ __device__ __forceinline__ float4* att() const { return arr(8); }         // attenuation                | w: bounce index j, bit 31 = NEE results pending, bit 30 = the last bounce was specular (directLight = -1, :469,480)
+    __host__ __device__ __forceinline__ float4* att() const { return arr(8); }         // attenuation                | w: bounce index j (28 bits), bit 31 = NEE results pending, bit 30 = the last bounce was specular (directLight = -1, :469,480), bits 29 / 28 = the NEE ray / the cosine probe was answered "not emissive" by its creator (no record written for it)
     __host__ __device__ __forceinline__ float4* total() const { return arr(9); }       // totalColor                 | w: samples finished for this pixel
     // (directLight has no record: between two segments it is either about to be recomputed from the probe results — bit 31 of
     // att.w — or one of two constants: -1 after a specular bounce, bit 30, and 0 at the start of a sample)
@@ -1194,7 +1194,7 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
     uint32_t state = __float_as_uint(sD.w);
     uint32_t jraw = __float_as_uint(sA.w);
     uint32_t samplesDone = __float_as_uint(sT.w);
-    uint32_t j = jraw & 0x3fffffffu;
+    uint32_t j = jraw & 0x0fffffffu;
     const bool pending = (jraw >> 31) != 0u;
     // directLight as the last segment left it (raytrace.comp:487,469,480,460): -1 after a specular bounce, 0 at the start of a
     // sample; after a diffuse bounce the block below recomputes it before it is read
@@ -1214,7 +1214,10 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
             // finish diffuseBRDF of the previous bounce (:443-460); its three
             // scene queries were the NEE ray (once for :443 and :447) and the
             // cosine probe (:453)
-            const float4 hL = ps.hit(RAY_NEE)[slot], hC = ps.hit(RAY_PROBE)[slot];
+            // (a light query its creator answered left no record: it is the record of a ray that hit nothing)
+            float4 hL = make_float4(RT_MISS_DST, __uint_as_float(RT_HIT_NONE), 0.f, 0.f), hC = hL;
+            if (!(jraw & 0x20000000u)) hL = ps.hit(RAY_NEE)[slot];
+            if (!(jraw & 0x10000000u)) hC = ps.hit(RAY_PROBE)[slot];
             const float4 aO = ps.auxO()[slot], aL = ps.auxDL()[slot], aC = ps.auxDC()[slot];
             float tL = hL.x, tC = hC.x;
             uint32_t oL = __float_as_uint(hL.y), oC = __float_as_uint(hC.y);
@@ -1378,12 +1381,13 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
                 if (!(tC < RT_MISS_DST) || sC.x < tC) { sC.x = RT_MISS_DST; sC.y = __uint_as_float(RT_HIT_NONE); auxMask &= ~2u; }
                 else sC.w = tC;
             }
-            ps.hit(RAY_NEE)[slot] = sL;
-            ps.hit(RAY_PROBE)[slot] = sC;
+            if (auxMask & 1u) ps.hit(RAY_NEE)[slot] = sL;     // the traversal's seed; an answered query needs no record (att.w bits 29 / 28)
+            if (auxMask & 2u) ps.hit(RAY_PROBE)[slot] = sC;
         }
+        const uint32_t answered = wantAux ? (((auxMask & 1u) ? 0u : 0x20000000u) | ((auxMask & 2u) ? 0u : 0x10000000u)) : 0u;
         ps.rayO()[slot] = mk4(ro, misW);
         ps.rayD()[slot] = mk4u(rd, state);
-        ps.att()[slot] = mk4u(att, j | (wantAux ? 0x80000000u : 0u) | (specular ? 0x40000000u : 0u));
+        ps.att()[slot] = mk4u(att, j | (wantAux ? 0x80000000u : 0u) | (specular ? 0x40000000u : 0u) | answered);
         ps.total()[slot] = mk4u(total, samplesDone);
     }
 }
