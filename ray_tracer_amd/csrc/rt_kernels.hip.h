@@ -1186,6 +1186,8 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
     bool wantAux = false;  // a diffuse bounce whose MIS the next segment finishes (raytrace.comp:443-460)
     auxMask = 0;
     rt_vec3 auxOrigin = rt_v3(0, 0, 0), auxL = auxOrigin, auxC = auxOrigin;  // probe rays of this bounce (diffuse only)
+    rt_vec3 auxAlbedo = auxOrigin;                                           // ... and what the next segment needs to finish its MIS
+    float auxNdotL = 0.f, auxCosPdfL = 0.f, auxCosPdfC = 0.f;
     const float4 sO = ps.rayO()[slot], sD = ps.rayD()[slot], sA = ps.att()[slot], sT = ps.total()[slot];
     const float4 hM = ps.hit(RAY_MAIN)[slot];
     rt_vec3 ro = f4xyz(sO), rd = f4xyz(sD);
@@ -1304,11 +1306,12 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
                 radiance = rt_v3(radiance.x / realCosinePDF, radiance.y / realCosinePDF, radiance.z / realCosinePDF);
                 sampledDir = cosineSample;
 
-                auxOrigin = origin; auxL = lightSample; auxC = cosineSample;
-                ps.auxO()[slot] = mk4(origin, rt_max(0.f, rt_dot(hit.normal, lightSample)));
-                ps.auxDL()[slot] = mk4(lightSample, rt_max(0.f, rt_dot(lightSample, hit.normal) * RT_INV_PI));
-                ps.auxDC()[slot] = mk4(cosineSample, realCosinePDF);
-                ps.pendAlbedo()[slot] = mk4(albedo, 0.f);
+                // (the four records of the unfinished MIS are written at the end, once it is known that the path goes on and that
+                // the next segment needs them)
+                auxOrigin = origin; auxL = lightSample; auxC = cosineSample; auxAlbedo = albedo;
+                auxNdotL = rt_max(0.f, rt_dot(hit.normal, lightSample));
+                auxCosPdfL = rt_max(0.f, rt_dot(lightSample, hit.normal) * RT_INV_PI);
+                auxCosPdfC = realCosinePDF;
             }
             att = rt_mul(att, radiance);
 
@@ -1381,8 +1384,26 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
                 if (!(tC < RT_MISS_DST) || sC.x < tC) { sC.x = RT_MISS_DST; sC.y = __uint_as_float(RT_HIT_NONE); auxMask &= ~2u; }
                 else sC.w = tC;
             }
-            if (auxMask & 1u) ps.hit(RAY_NEE)[slot] = sL;     // the traversal's seed; an answered query needs no record (att.w bits 29 / 28)
-            if (auxMask & 2u) ps.hit(RAY_PROBE)[slot] = sC;
+            const bool albedoFinite = !(rt_isnan(auxAlbedo.x) || rt_isnan(auxAlbedo.y) || rt_isnan(auxAlbedo.z) || rt_isinf(auxAlbedo.x) || rt_isinf(auxAlbedo.y) || rt_isinf(auxAlbedo.z));
+            if ((auxMask & 3u) == 0u && albedoFinite) {
+                // Both queries are answered "not emissive": the next segment's share of diffuseBRDF (:443-460) is known now.
+                // realLightPDF = 0 gives k = 0, so directLight = emission * ((albedo / pi * nDotL) * 0) = +-0 (emitMode: every
+                // material's emission is finite; the albedo is, checked above; nDotL = max(0, .) is) — and adding +-0 * attenuation
+                // to totalColor is adding +0 * attenuation, which is what a segment without pending results does. lightPDF = 0
+                // leaves cosineMisWeight = c^2 / (0 * 0 + c^2) with c = cosineHemispherePDF(n, cosineSample), the very expression of
+                // the pending block. So this bounce is finished here: no records, nothing pending.
+                float m2 = auxCosPdfC * auxCosPdfC / (0.f * 0.f + auxCosPdfC * auxCosPdfC);
+                if (rt_isnan(m2)) m2 = 0.f;
+                misW = m2;
+                wantAux = false;
+            } else {
+                if (auxMask & 1u) ps.hit(RAY_NEE)[slot] = sL;     // the traversal's seed; an answered query needs no record (att.w bits 29 / 28)
+                if (auxMask & 2u) ps.hit(RAY_PROBE)[slot] = sC;
+                ps.auxO()[slot] = mk4(auxOrigin, auxNdotL);
+                ps.auxDL()[slot] = mk4(auxL, auxCosPdfL);
+                ps.auxDC()[slot] = mk4(auxC, auxCosPdfC);
+                ps.pendAlbedo()[slot] = mk4(auxAlbedo, 0.f);
+            }
         }
         const uint32_t answered = wantAux ? (((auxMask & 1u) ? 0u : 0x20000000u) | ((auxMask & 2u) ? 0u : 0x10000000u)) : 0u;
         ps.rayO()[slot] = mk4(ro, misW);
