@@ -29,6 +29,7 @@ struct DevBuf {
 
 struct EventPair { hipEvent_t a, b; };
 // device-side {index,triCount} of a mesh root, keyed by its reference node index
+#define RT_MAX_LANES 4
 #define RT_FRAMES_MAX_SLOTS (24ull << 20)   // default for the paths of one multi-frame dispatch (ten 1080p frames or three 4K frames: 5.8 GB of path state)
 struct RootInfo { uint32_t idx, cnt; float lo[3], hi[3]; uint32_t triFirst, triTotal; };  // triTotal = ~0u: the mesh's triangles are not one contiguous range
 
@@ -60,7 +61,19 @@ struct rt_ctx {
     std::vector<RootInfo> rootOf;             // per reference node; idx = ~0u unless a mesh root
 
     // path state
-    DevBuf stateBuf, queueBuf, fbBuf, counterBuf, scratchBuf, overflowBuf;
+    DevBuf stateBuf, queueBuf, fbBuf, counterBuf, scratchBuf, overflowBuf, overflowBufSide[RT_MAX_LANES - 1];
+    // Multi-kernel pipeline in `lanes` independent parts (render_impl): the paths of a dispatch are split into contiguous slot
+    // ranges, each with its own queues, counters and stream, so that one part's k_shade and the tail of its k_trace_pw launch
+    // run under the other part's traversal. Part 0 is the ctx stream itself; the others fork from it and join it.
+    hipStream_t sideStream[RT_MAX_LANES - 1] = {};
+    hipEvent_t forkEvent = nullptr, joinEvent[RT_MAX_LANES - 1] = {}, pollEventSide[RT_MAX_LANES - 1] = {};
+    int lanes = 3;                        // rt_set_tuning("lanes", 1..RT_MAX_LANES)
+    uint32_t lanesMinSlots = 1u << 20;    // dispatches of fewer paths than this stay in one part
+    hipStream_t curStream = nullptr;      // the stream and counters of the part whose launches are being built (launch_trace)
+    uint32_t* curCounts = nullptr;
+    int curLane = 0;
+    int curGridPct = 100;                 // share of the resident work-groups a k_trace_pw launch of the current part takes
+    int laneGridPct = 50;                 // rt_set_tuning("lane_grid_pct"): that share while a dispatch runs in several parts
     uint32_t capacity = 0;  // pixels the state buffers hold
     PathState ps{};
     Queues q{};
@@ -222,28 +235,32 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
         if (e != hipSuccess || perCU <= 0) perCU = 4;
     }
     uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
-    uint32_t blocks = std::min((maxRays + RT_BLOCK - 1) / RT_BLOCK, resident);
+    // a part of a dispatch that runs beside the other parts' launches takes its share of the resident work-groups (curGridPct)
+    uint32_t blocks = std::min((maxRays + RT_BLOCK - 1) / RT_BLOCK, std::max(1u, (uint32_t)((uint64_t)resident * (uint32_t)c->curGridPct / 100u)));
     uint32_t* overflow = nullptr;
+    hipStream_t stream = c->curStream ? c->curStream : c->stream;
+    uint32_t* laneCounts = c->curCounts ? c->curCounts : c->q.counts;
     if (OVF) {
         const size_t need = (size_t)(c->maxLeafDepth - STACK) * resident * RT_BLOCK * 4;
-        int rc = dev_alloc(c, c->overflowBuf, need);
+        DevBuf& ob = c->curLane ? c->overflowBufSide[c->curLane - 1] : c->overflowBuf;   // launches of different parts run at the same time
+        int rc = dev_alloc(c, ob, need);
         if (rc) return rc;
-        overflow = (uint32_t*)c->overflowBuf.p;
+        overflow = (uint32_t*)ob.p;
     }
     unsigned long long* waveTimes = nullptr;
-    if (c->phaseStats) {
+    if (c->phaseStats == 1 || (c->phaseStats >= 2 && c->traceLaunchesTotal == (uint64_t)(c->phaseStats - 2))) {  // 1: the last launch's waves; 2 + k: launch k's (after rt_reset_counters)
         c->waveTimesCount = (size_t)blocks * (RT_BLOCK / RT_WAVE);
         int rc = dev_alloc(c, c->waveTimeBuf, c->waveTimesCount * 16);
         if (rc) return rc;
         waveTimes = (unsigned long long*)c->waveTimeBuf.p;
     }
-    TracePwArgs pa{ta.queue, ta.count, c->q.counts + 4, (uint32_t)c->refillMk, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, (uint32_t)c->fastShare,
+    TracePwArgs pa{ta.queue, ta.count, laneCounts + 4, (uint32_t)c->refillMk, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, (uint32_t)c->fastShare,
                    ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), waveTimes, overflow};
-    if (hotMode == 1) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL, HOT6, 6>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
-    else if (hotMode == 2) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL, HOT5, 5>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
-    else if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, true, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
-    else if (pix) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, false, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
-    else hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, pa);
+    if (hotMode == 1) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL, HOT6, 6>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
+    else if (hotMode == 2) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL, HOT5, 5>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
+    else if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, true, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
+    else if (pix) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, false, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
+    else hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
     return 0;
 }
 
@@ -358,12 +375,13 @@ int launch_fused(rt_ctx* c, const FrameParams& fp, float4* fb) {
 template <int STACK>
 void launch_v0_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     uint32_t blocks = (maxRays + RT_BLOCK - 1) / RT_BLOCK;
-    hipLaunchKernelGGL((k_trace<STACK>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, ta);
+    hipLaunchKernelGGL((k_trace<STACK>), dim3(blocks), dim3(RT_BLOCK), 0, c->curStream ? c->curStream : c->stream, c->sc, c->ps, ta);
 }
 
 // the work counter (counts[4]) must be zero when this is called
 int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     if (maxRays == 0) return 0;
+    hipStream_t stream = c->curStream ? c->curStream : c->stream;
     EventPair* ev = nullptr;
     if (c->profiling) {
         if (c->evUsed == c->evPool.size()) {
@@ -373,7 +391,7 @@ int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
             c->evPool.push_back(p);
         }
         ev = &c->evPool[c->evUsed++];
-        RT_HIP(c, hipEventRecord(ev->a, c->stream));
+        RT_HIP(c, hipEventRecord(ev->a, stream));
     }
     const uint32_t d = c->maxLeafDepth;
     int rc = 0;
@@ -405,7 +423,7 @@ int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     }
     if (rc) return rc;
     RT_HIP(c, hipGetLastError());
-    if (ev) RT_HIP(c, hipEventRecord(ev->b, c->stream));
+    if (ev) RT_HIP(c, hipEventRecord(ev->b, stream));
     c->traceLaunchesTotal++;
     return 0;
 }
@@ -502,8 +520,8 @@ int rt_create(int device, rt_ctx** out) {
     if (hipHostMalloc((void**)&c->snap, sizeof(DevCounters), hipHostMallocDefault) != hipSuccess) { c->snap = nullptr; rt_destroy(c); return -6; }
     if (hipEventCreateWithFlags(&c->snapEvent, hipEventDisableTiming) != hipSuccess) { c->snapEvent = nullptr; rt_destroy(c); return -6; }
     if (hipEventCreateWithFlags(&c->pollEvent, hipEventDisableTiming) != hipSuccess) { c->pollEvent = nullptr; rt_destroy(c); return -6; }
-    if (dev_alloc(c, c->counterBuf, sizeof(DevCounters) + 128) != 0) { rt_destroy(c); return -7; }
-    (void)hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 128, c->stream);
+    if (dev_alloc(c, c->counterBuf, sizeof(DevCounters) + 256) != 0) { rt_destroy(c); return -7; }
+    (void)hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 256, c->stream);
     (void)hipStreamSynchronize(c->stream);
     *out = c;
     return 0;
@@ -524,6 +542,13 @@ void rt_destroy(rt_ctx* c) {
     if (c->snap) (void)hipHostFree(c->snap);
     if (c->snapEvent) (void)hipEventDestroy(c->snapEvent);
     if (c->pollEvent) (void)hipEventDestroy(c->pollEvent);
+    if (c->forkEvent) (void)hipEventDestroy(c->forkEvent);
+    for (int l = 0; l < RT_MAX_LANES - 1; l++) {
+        if (c->joinEvent[l]) (void)hipEventDestroy(c->joinEvent[l]);
+        if (c->pollEventSide[l]) (void)hipEventDestroy(c->pollEventSide[l]);
+        if (c->sideStream[l]) (void)hipStreamDestroy(c->sideStream[l]);
+        dev_free(c->overflowBufSide[l]);
+    }
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -661,7 +686,14 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
             wbox[2 * (size_t)i + 1] = make_float4(r.hi[0], r.hi[1], r.hi[2], 0.f);   // this saves are the cheap ones (profiles/README.md)
             boxOk = 4u;
         }
-        meta[i] = make_uint4(r.idx, r.cnt, o[i].materialIndex, (isIdent ? 1u : 0u) | boxOk | ((o[i].samplerIndex & 0xffffu) << 16));
+        // bit 3: the matrix itself is exactly the identity as well (reconstruct_hit then applies neither matrix)
+        bool fwdIdent = isIdent;
+        for (int r4 = 0; r4 < 3; r4++) {
+            const float4& q = fwd[3 * (size_t)i + r4];
+            const float qq[4] = {q.x, q.y, q.z, q.w};
+            for (int k4 = 0; k4 < 4; k4++) fwdIdent = fwdIdent && (qq[k4] == ident[r4 * 4 + k4]);
+        }
+        meta[i] = make_uint4(r.idx, r.cnt, o[i].materialIndex, (isIdent ? 1u : 0u) | boxOk | (fwdIdent ? 8u : 0u) | ((o[i].samplerIndex & 0xffffu) << 16));
         {   // flags and root triangle count ride in the box's w components (one fetch per object in the skipping loop)
             const uint32_t fl = meta[i].w & 0xffffu, cn = r.cnt;
             memcpy(&wbox[2 * (size_t)i].w, &fl, 4);
@@ -951,9 +983,9 @@ int probe_ray_cost(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t 
     RT_HIP(c, hipMemcpyAsync(&before, c->counterBuf.p, sizeof(DevCounters), hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     const int pipeline = c->pipeline, lastPipeline = c->lastPipeline, lastBatch = c->lastBatchPixels;
-    const bool profiling = c->profiling, phaseStats = c->phaseStats;
+    const bool profiling = c->profiling; const int phaseStats = c->phaseStats;
     const uint64_t launches = c->traceLaunchesTotal;
-    c->pipeline = 1; c->profiling = false; c->phaseStats = false; c->inProbe = true;
+    c->pipeline = 1; c->profiling = false; c->phaseStats = 0; c->inProbe = true;
     rc = rt_render(c, &p, width, height, row0 + (skip / 2u) * rowStride, rowStride * skip, rows, (float*)c->probeBuf.p);
     c->pipeline = pipeline; c->profiling = profiling; c->phaseStats = phaseStats; c->inProbe = false;
     c->lastPipeline = lastPipeline; c->lastBatchPixels = lastBatch; c->traceLaunchesTotal = launches;
@@ -1042,7 +1074,6 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
     const uint32_t blocksPix = (nPixels + RT_BLOCK - 1) / RT_BLOCK;
     // several frames in one dispatch: the paths are {64 tile slots} x {frames} (FrameParams::nFrames), in either pipeline
     const uint32_t nSlots = nFrames > 1u ? (nPixels + 63u) / 64u * 64u * nFrames : nPixels;
-    const uint32_t blocksSlots = (nSlots + RT_BLOCK - 1) / RT_BLOCK;
     DevCounters* dc = (DevCounters*)c->counterBuf.p;
     uint32_t* counts = c->q.counts;
 
@@ -1072,44 +1103,98 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
         if (!rc) request_ray_cost(c);
         return rc;
     }
-    hipLaunchKernelGGL(k_raygen, dim3(blocksSlots), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, c->q, fp);
+    // The dispatch in `nLanes` independent parts: contiguous slot ranges (whole 256-slot blocks of all the frames of a tile
+    // block), each with its own region of the queues, its own counters and its own stream. A pixel's path depends on nothing but
+    // its slot, so the parts give the same bits as the whole; what they buy is overlap: one part's k_shade (bound by the path
+    // state it streams) and the draining tail of its k_trace_pw launch run under the other part's traversal (bound by latency).
+    // Part 0 runs on the ctx stream, the others fork from it after the ray generation and join it before the image is written.
+    int nLanes = (fp.samples > 0 && nSlots >= c->lanesMinSlots) ? std::max(1, std::min(c->lanes, (int)RT_MAX_LANES)) : 1;
+    if (c->phaseStats) nLanes = 1;  // the diagnostic kernel's statistics are per launch
+    for (int l = 1; l < nLanes; l++) {
+        if (!c->sideStream[l - 1]) {
+            if (hipStreamCreateWithFlags(&c->sideStream[l - 1], hipStreamNonBlocking) != hipSuccess) { c->sideStream[l - 1] = nullptr; nLanes = l; break; }
+            if (hipEventCreateWithFlags(&c->joinEvent[l - 1], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->pollEventSide[l - 1], hipEventDisableTiming) != hipSuccess) { nLanes = l; break; }
+        }
+    }
+    if (nLanes > 1 && !c->forkEvent && hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming) != hipSuccess) { c->forkEvent = nullptr; nLanes = 1; }
+    struct Lane {
+        hipStream_t stream; uint32_t* counts; hipEvent_t poll; uint32_t begin, n, ubActive; int cur; bool pollPending, done;
+    } lane[RT_MAX_LANES];
+    {
+        const uint32_t unit = 256u * std::max(1u, nFrames);  // whole blocks of k_shade, whole tile blocks of all their frames
+        const uint32_t units = (nSlots + unit - 1) / unit;
+        uint32_t at = 0;
+        for (int l = 0; l < nLanes; l++) {
+            const uint32_t u = units / (uint32_t)nLanes + ((uint32_t)l < units % (uint32_t)nLanes ? 1u : 0u);
+            const uint32_t end = std::min(nSlots, at + u * unit);
+            lane[l] = Lane{l ? c->sideStream[l - 1] : c->stream, counts + 8 * l, l ? c->pollEventSide[l - 1] : c->pollEvent, at, end - at, end - at, 0, false, end == at};
+            at = end;
+        }
+    }
+    for (int l = 0; l < nLanes; l++) {
+        const Lane& L = lane[l];
+        if (!L.n) continue;
+        hipLaunchKernelGGL(k_raygen, dim3((L.n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps,
+                           c->q.active[0] + L.begin, c->q.rays[0] + 3 * (size_t)L.begin, fp, L.begin, L.begin + L.n);
+        // counts: [0],[1] active paths of buffer 0/1; [2],[3] rays of buffer 0/1; [4] the traversal's work counter
+        if (fp.samples > 0) hipLaunchKernelGGL(k_init_counts, dim3(1), dim3(64), 0, c->stream, L.counts, L.n);
+    }
     RT_HIP(c, hipGetLastError());
 
     if (fp.samples > 0) {
-        // counts: [0],[1] active paths of buffer 0/1; [2],[3] rays of buffer 0/1; [4] the traversal's work counter
-        hipLaunchKernelGGL(k_init_counts, dim3(1), dim3(64), 0, c->stream, counts, nSlots);
-
+        if (nLanes > 1) {
+            RT_HIP(c, hipEventRecord(c->forkEvent, c->stream));
+            for (int l = 1; l < nLanes; l++) RT_HIP(c, hipStreamWaitEvent(lane[l].stream, c->forkEvent, 0));
+        }
         // The whole dispatch is enqueued without waiting for the device (rt_amd.h: "asynchronous on the ctx stream"): every
         // kernel reads its queue length from device memory and leaves at once when the queue is empty, so the loop may
         // simply run to the most rounds a pixel can need, samples * (bounceLimit + 1). The active-path count is copied
         // back now and then without ever being waited for; a copy that has arrived shrinks the grids of the launches still
-        // to be enqueued (active paths never increase, so a stale count is a valid upper bound) and ends the loop at zero.
-        uint32_t ubActive = nSlots;
-        int cur = 0;
+        // to be enqueued (active paths never increase, so a stale count is a valid upper bound) and ends the part at zero.
         const uint64_t maxRounds = (uint64_t)fp.samples * ((uint64_t)fp.bounceLimit + 1);
-        bool pollPending = false;
+        struct LaneGuard {  // launch_trace builds its launches for the part named here
+            rt_ctx* c;
+            ~LaneGuard() { c->curStream = nullptr; c->curCounts = nullptr; c->curLane = 0; c->curGridPct = 100; }
+        } laneGuard{c};
+        c->curGridPct = nLanes > 1 ? c->laneGridPct : 100;
         for (uint64_t it = 0; it < maxRounds; it++) {
-            const int nxt = cur ^ 1;
-            hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, c->stream, counts + nxt, counts + 2 + nxt, counts + 4);
-            TraceArgs ta{c->q.rays[cur], counts + 2 + cur, nullptr, nullptr, dc};
-            uint64_t ubRays = std::min<uint64_t>((uint64_t)ubActive * 3, (uint64_t)nSlots * 3);
-            if ((rc = launch_trace(c, (uint32_t)ubRays, ta))) return rc;
-            ShadeArgs sa{c->q.active[cur], counts + cur, c->q.active[nxt], c->q.rays[nxt], counts + nxt, counts + 2 + nxt, dc};
-            hipLaunchKernelGGL(k_shade, dim3((ubActive + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps, sa, fp);
-            cur = nxt;
-            if (pollPending && hipEventQuery(c->pollEvent) == hipSuccess) {
-                pollPending = false;
-                ubActive = std::min(ubActive, c->hostCounts[8]);
-                if (ubActive == 0) break;
+            bool any = false;
+            for (int l = 0; l < nLanes; l++) {
+                Lane& L = lane[l];
+                if (L.done) continue;
+                any = true;
+                c->curStream = L.stream; c->curCounts = L.counts; c->curLane = l;
+                const int cur = L.cur, nxt = cur ^ 1;
+                uint32_t* const active[2] = {c->q.active[0] + L.begin, c->q.active[1] + L.begin};
+                uint32_t* const rays[2] = {c->q.rays[0] + 3 * (size_t)L.begin, c->q.rays[1] + 3 * (size_t)L.begin};
+                hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, L.stream, L.counts + nxt, L.counts + 2 + nxt, L.counts + 4);
+                TraceArgs ta{rays[cur], L.counts + 2 + cur, nullptr, nullptr, dc};
+                const uint64_t ubRays = std::min<uint64_t>((uint64_t)L.ubActive * 3, (uint64_t)L.n * 3);
+                if ((rc = launch_trace(c, (uint32_t)ubRays, ta))) break;
+                ShadeArgs sa{active[cur], L.counts + cur, active[nxt], rays[nxt], L.counts + nxt, L.counts + 2 + nxt, dc};
+                hipLaunchKernelGGL(k_shade, dim3((L.ubActive + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, L.stream, c->sc, c->ps, sa, fp);
+                L.cur = nxt;
+                if (L.pollPending && hipEventQuery(L.poll) == hipSuccess) {
+                    L.pollPending = false;
+                    L.ubActive = std::min(L.ubActive, c->hostCounts[8 + l]);
+                    if (L.ubActive == 0) { L.done = true; continue; }
+                }
+                if (!L.pollPending && (it & 7u) == 7u) {
+                    if (hipMemcpyAsync(c->hostCounts + 8 + l, L.counts + L.cur, 4, hipMemcpyDeviceToHost, L.stream) == hipSuccess &&
+                        hipEventRecord(L.poll, L.stream) == hipSuccess)
+                        L.pollPending = true;
+                }
             }
-            if (!pollPending && (it & 7u) == 7u) {
-                if (hipMemcpyAsync(c->hostCounts + 8, counts + cur, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-                    hipEventRecord(c->pollEvent, c->stream) == hipSuccess)
-                    pollPending = true;
-            }
+            if (!any || rc) break;
         }
         // (a copy still in flight when the loop ends is harmless: the stream orders it before the next dispatch's own
         // copies, and the slot is only read after the event of the copy that filled it)
+        for (int l = 1; l < nLanes; l++) {  // (also when a launch failed: nothing of this dispatch is left running beside the ctx stream)
+            RT_HIP(c, hipEventRecord(c->joinEvent[l - 1], lane[l].stream));
+            RT_HIP(c, hipStreamWaitEvent(c->stream, c->joinEvent[l - 1], 0));
+        }
+        if (rc) return rc;
     }
     if (nFrames > 1u) hipLaunchKernelGGL(k_blend_frames, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->ps, fp, fb);
     else hipLaunchKernelGGL(k_resolve, dim3(blocksPix), dim3(RT_BLOCK), 0, c->stream, c->ps, fp, fb);
@@ -1231,13 +1316,15 @@ int rt_get_counters(rt_ctx* c, RtCounters* out) {
     out->traceLaunches = c->traceLaunchesTotal;
     out->emitterTests = h.emitterTests;
     if (c->phaseStats) {
-        unsigned long long ps[15];
+        unsigned long long ps[20];
         RT_HIP(c, hipMemcpy(ps, (char*)c->counterBuf.p + sizeof(DevCounters), sizeof(ps), hipMemcpyDeviceToHost));
         static const char* nm[4] = {"refill", "setup", "interior", "leaf"};
         for (int k = 0; k < 4; k++)
             fprintf(stderr, "[phase_stats] %-8s rounds %12llu lanes %14llu avg active %.1f  clocks/round %8.0f  share of wave time %.1f %%\n", nm[k], ps[k], ps[4 + k],
                     ps[k] ? (double)ps[4 + k] / ps[k] : 0.0, ps[k] ? (double)ps[8 + k] / ps[k] : 0.0,
                     100.0 * ps[8 + k] / std::max(1.0, (double)(ps[8] + ps[9] + ps[10] + ps[11])));
+        fprintf(stderr, "[phase_stats] clocks per round from the step's first load to its data: refill (queue entry, incl. the atomic) %.0f, setup (ray, seed) %.0f, interior (child pair) %.0f, leaf (triangles) %.0f\n",
+                ps[0] ? (double)ps[16] / ps[0] : 0.0, ps[1] ? (double)ps[17] / ps[1] : 0.0, ps[2] ? (double)ps[18] / ps[2] : 0.0, ps[3] ? (double)ps[19] / ps[3] : 0.0);
         fprintf(stderr, "[phase_stats] lanes sitting out interior rounds: %.1f at a leaf, %.1f in set-up states, %.1f without a ray (of 64, average)\n",
                 ps[2] ? (double)ps[12] / ps[2] : 0.0, ps[2] ? (double)ps[13] / ps[2] : 0.0, ps[2] ? (double)ps[14] / ps[2] : 0.0);
         if (c->waveTimesCount && c->waveTimeBuf.p) {  // the last k_trace_pw launch: when did its waves finish?
@@ -1263,7 +1350,7 @@ int rt_reset_counters(rt_ctx* c) {
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     poll_ray_cost(c);  // a snapshot of the last dispatch's counters has arrived by now: what it says about the scene's rays is kept
-    RT_HIP(c, hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 128, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 256, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->snapPending = false;
     c->snapBox = 0; c->snapRays = 0;
@@ -1318,7 +1405,10 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "pixel_refill") { if (value < 0 || value > (int)RT_WAVE) return c->fail("pixel_refill must be 0 (by ray length) .. 64"); c->pixelRefill = value; }
     else if (k == "batch_pixels") { if (value < 0 || value > (int)RT_WAVE) return c->fail("batch_pixels must be 0 (auto) .. 64"); c->batchPixels = value; }
     else if (k == "batch_fixed") { if (value < 0 || value > 4096) return c->fail("batch_fixed out of range"); c->batchFixed = value; }
-    else if (k == "phase_stats") { c->phaseStats = value != 0; }
+    else if (k == "phase_stats") { if (value < 0) return c->fail("phase_stats >= 0"); c->phaseStats = value; }
+    else if (k == "lanes") { if (value < 1 || value > RT_MAX_LANES) return c->fail("lanes: 1..4 (parts of a multi-kernel dispatch, each on its own stream)"); c->lanes = value; }
+    else if (k == "lane_grid_pct") { if (value < 10 || value > 100) return c->fail("lane_grid_pct: 10..100"); c->laneGridPct = value; }
+    else if (k == "lanes_min_kslots") { if (value < 0) return c->fail("lanes_min_kslots >= 0"); c->lanesMinSlots = (uint32_t)value << 10; }
     else if (k == "blocks_per_cu") { if (value < 0 || value > 8) return c->fail("blocks_per_cu: 0..8"); c->blocksPerCU = value; }
     else return c->fail("unknown tuning key " + k);
     return 0;

@@ -28,6 +28,21 @@
 #include "rt_probe.h"
 
 #define RT_WAVE 64
+#ifndef RT_PRELOAD_TOP
+#define RT_PRELOAD_TOP 0   // trace_wave: the stack top a round's tail may pop is read at the start of the round
+#endif
+#ifndef RT_TE_REG
+#define RT_TE_REG 1        // trace_wave: a light query's tE rides in a register instead of being re-read from the hit record when a leaf step finds a hit
+#endif
+#ifndef RT_HOT_AS
+#define RT_HOT_AS 0        // trace_wave: LDS and global loads of a child pair kept apart by address space (no FLAT instructions)
+#endif
+#ifndef RT_TRI_X4
+#define RT_TRI_X4 1        // trace_wave, leaf step: a triangle's positions as three aligned dwordx4 loads
+#endif
+#ifndef RT_SHADE_IDENT
+#define RT_SHADE_IDENT 1   // reconstruct_hit: no matrix loads / transforms for identity-transform objects hit by a plain ray
+#endif
 #define RT_BLOCK 256
 #define RT_LEAF_BIT 0x80000000u
 #define RT_HIT_NONE 0xffffffffu
@@ -175,6 +190,9 @@ struct DevCounters {
 //   rt_global(p):  read-only tables indexed per lane (materials, objects, triangles) -> global address space -> global_load.
 #define RT_AS_CONSTANT __attribute__((address_space(4)))
 #define RT_AS_GLOBAL __attribute__((address_space(1)))
+#define RT_AS_LDS __attribute__((address_space(3)))
+typedef float rt_f4v __attribute__((ext_vector_type(4)));
+typedef float rt_f2v __attribute__((ext_vector_type(2)));
 template <typename T> __device__ __forceinline__ const T* rt_uniform(const T* p) { return (const T*)(const RT_AS_CONSTANT T*)(unsigned long long)p; }
 template <typename T> __device__ __forceinline__ const T* rt_global(const T* p) { return (const T*)(const RT_AS_GLOBAL T*)(unsigned long long)p; }
 
@@ -247,6 +265,13 @@ __device__ __forceinline__ bool ray_is_plain(rt_vec3 wo, rt_vec3 wd) {
     return ((rt_f2u(wd.x) & M) - 1u < E - 1u) && ((rt_f2u(wd.y) & M) - 1u < E - 1u) && ((rt_f2u(wd.z) & M) - 1u < E - 1u) &&
            ((rt_f2u(wo.x) & M) < E) && ((rt_f2u(wo.y) & M) < E) && ((rt_f2u(wo.z) & M) < E) &&
            rt_f2u(wo.x) != 0x80000000u && rt_f2u(wo.y) != 0x80000000u && rt_f2u(wo.z) != 0x80000000u;
+}
+
+// A vector the identity matrix maps to itself bit for bit: every component finite and none a negative zero
+__device__ __forceinline__ bool vec_is_plain(rt_vec3 v) {
+    const uint32_t E = 0x7f800000u, M = 0x7fffffffu;
+    return ((rt_f2u(v.x) & M) < E) && ((rt_f2u(v.y) & M) < E) && ((rt_f2u(v.z) & M) < E) &&
+           rt_f2u(v.x) != 0x80000000u && rt_f2u(v.y) != 0x80000000u && rt_f2u(v.z) != 0x80000000u;
 }
 
 // What the creator of a ray hands to the traversal (hit record of the ray's kind): the closest sphere hit (the shader's
@@ -597,11 +622,15 @@ struct TracePwArgs {
     uint32_t* overflow;       // OVF only: stack entries beyond STACK, (maxDepth - STACK) x resident lanes
 };
 
+// STATS: wait for every outstanding load, then read the clock (splits a step's time into "data on its way" and the rest)
+#define RT_STAMP_AFTER_LOADS(acc, t0) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); (acc) += clock64() - (t0); } while (0)
+
 // Counters a wave accumulates while it traces (reduced once per kernel).
 struct WaveTotals {
     uint32_t totBox = 0, totTri = 0, totRays = 0, totHits = 0;
     uint32_t dbgRounds[4] = {0, 0, 0, 0}, dbgLanes[4] = {0, 0, 0, 0};  // refill, setup, interior, leaf (STATS)
     unsigned long long dbgCycles[4] = {0, 0, 0, 0};                    // shader clocks spent in rounds of each kind (STATS)
+    unsigned long long dbgLoad[4] = {0, 0, 0, 0};                      // ... of which: from the step's first load instruction to the arrival of its data (STATS)
     uint32_t dbgWait[3] = {0, 0, 0};  // STATS: lanes that sat out interior rounds at a leaf / in set-up states / without a ray
 };
 
@@ -644,6 +673,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
     uint32_t thr = ta.fastLanes;
 
     uint32_t reach = 0xffffffffu;  // objects (of the mask's window) the ray has to enter, from its creator (sphere_seed)
+    float earlyT = 0.f;            // light queries: tE, the distance of the nearest emissive primitive on the ray (0: any other ray)
 
     // Called right after `obj` moved past the object that is being entered: obj - 1 is the object under traversal. The
     // objects after it that the ray's mask rules out are jumped over here (two box tests each, nothing else), and how many
@@ -679,6 +709,13 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
     for (;;) {
         const unsigned long long tRound = STATS ? clock64() : 0ull;
         int roundKind = 2;
+#if RT_PRELOAD_TOP
+        // The stack entry the tail may pop, read before the round's step instead of after it: a lane that pushes in the interior
+        // step goes on into the near child (dFar < best implies dNear < best) and never pops in the same round, and no other step
+        // pushes at all, so whenever the tail pops, the top of the stack is what it was here. One LDS round trip less on the
+        // dependent chain of every round (the read now returns while the round's node fetch is in flight).
+        const uint32_t topPre = stack[(OVF ? min((sp ? sp : 1u) - 1u, (uint32_t)STACK) : (sp ? sp : 1u) - 1u) * RT_WAVE];
+#endif
         const unsigned long long mI = __ballot((int32_t)cur >= 0);
         uint32_t nI = __popcll(mI);
         bool runI = nI >= thr;
@@ -713,6 +750,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         cur = (!LOCAL && id == 0xffffffffu) ? RT_CUR_IDLE : RT_CUR_INIT;  // RT_QUEUE_HOLE: no ray behind this entry (k_raygen)
                     }
                 }
+                if (STATS) RT_STAMP_AFTER_LOADS(wt.dbgLoad[0], tRound);
                 resBase += take;
                 resCount -= take;
             }
@@ -730,6 +768,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                 roundKind = runI ? 2 : runL ? 3 : runS ? 1 : 0;
             }
 
+            const unsigned long long tLeaf = STATS ? clock64() : 0ull;
             if (runL) {
                 // ---------------- leaf step: up to two triangles (all of them for a leaf with > 7)
                 if ((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX) {
@@ -750,13 +789,27 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     if (cnt != 0u) {
                         // one or two triangles: both fetched before either is tested
                         const uint32_t j1 = jEnd - 1u;
+#if RT_TRI_X4
+                        // Whole 16-byte vectors from the global address space: three aligned loads per triangle. (Through float4, whose
+                        // padding words are never read, the compiler fetched a triangle's 44 bytes as 8 + 16 at offset 4 + 8 + 12: four
+                        // instructions, one of them straddling two 16-byte slots.)
+                        const RT_AS_GLOBAL rt_f4v* tp0 = (const RT_AS_GLOBAL rt_f4v*)sc.triPos + 3 * (size_t)j;
+                        const RT_AS_GLOBAL rt_f4v* tp1 = (const RT_AS_GLOBAL rt_f4v*)sc.triPos + 3 * (size_t)j1;
+                        const rt_f4v a0 = tp0[0], b0 = tp0[1], c0 = tp0[2];
+                        const rt_f4v a1 = tp1[0], b1 = tp1[1], c1 = tp1[2];
+#else
                         const float4 a0 = sc.triPos[3 * (size_t)j], b0 = sc.triPos[3 * (size_t)j + 1], c0 = sc.triPos[3 * (size_t)j + 2];
                         const float4 a1 = sc.triPos[3 * (size_t)j1], b1 = sc.triPos[3 * (size_t)j1 + 1], c1 = sc.triPos[3 * (size_t)j1 + 2];
+#endif
+                        if (STATS) RT_STAMP_AFTER_LOADS(wt.dbgLoad[3], tLeaf);
                         const rt_vec3 o = rt_v3(troXY.x, troXY.y, zOI.x);
-                        const TriHit h0 = tri_intersect(o, trd, f4xyz(a0), f4xyz(b0), f4xyz(c0), __float_as_uint(a0.w) != 0u);
+                        const TriHit h0 = tri_intersect(o, trd, rt_v3(a0.x, a0.y, a0.z), rt_v3(b0.x, b0.y, b0.z), rt_v3(c0.x, c0.y, c0.z), __float_as_uint(a0.w) != 0u);
                         if (h0.didHit && h0.dst < best) { best = h0.dst; bestObj = cur_object(); bestTri = j; closer = true; }
-                        if (j1 != j) {
-                            const TriHit h1 = tri_intersect(o, trd, f4xyz(a1), f4xyz(b1), f4xyz(c1), __float_as_uint(a1.w) != 0u);
+                        // (a one-triangle step tests its triangle twice, which changes nothing — the second result can never win the strict
+                        // `<` against the first — and keeps both triangles' loads in one block ahead of both tests: with the second test
+                        // behind a branch the compiler moved the second triangle's loads behind the first test, two round trips per step)
+                        if (!RT_TRI_X4 ? j1 != j : true) {
+                            const TriHit h1 = tri_intersect(o, trd, rt_v3(a1.x, a1.y, a1.z), rt_v3(b1.x, b1.y, b1.z), rt_v3(c1.x, c1.y, c1.z), __float_as_uint(a1.w) != 0u);
                             if (h1.didHit && h1.dst < best) { best = h1.dst; bestObj = cur_object(); bestTri = j1; closer = true; }
                         }
                     } else {
@@ -771,7 +824,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     // is "not emissive" whatever else the ray meets, so it ends here and reports no hit, which is what shade_path
                     // reads as "not emissive". tE is re-read from the ray's hit record on the rare step that finds a hit rather
                     // than held in a register through the loop. The leaf counts in full, as the shader counts it (:310).
-                    if (closer && best < ps.hit(id & 3u)[id >> 2].w) {
+                    if (closer && best < (RT_TE_REG ? earlyT : ps.hit(id & 3u)[id >> 2].w)) {
                         if ((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX) {  // triangles of this leaf not yet stepped through
                             const uint32_t rest = (cur >> RT_LEAF_CNT_SHIFT) & 7u;
                             if (PIX) rayTri += rest; else wt.totTri += rest;
@@ -800,12 +853,18 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     rt_vec3 wo, wd;
                     if (kind == RAY_MAIN) { wo = f4xyz(ps.rayO()[slot]); wd = f4xyz(ps.rayD()[slot]); }
                     else { wo = f4xyz(ps.auxO()[slot]); wd = f4xyz(kind == RAY_NEE ? ps.auxDL()[slot] : ps.auxDC()[slot]); }
+                    float4 seedPre = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (STATS) {  // the ray and its seed, all on their way at once, then the stamp
+                        if (cur == RT_CUR_INIT) seedPre = ps.hit(kind)[slot];
+                        RT_STAMP_AFTER_LOADS(wt.dbgLoad[1], tLeaf);
+                    }
                     if (cur == RT_CUR_INIT) {
                         // the ray's creator already ran the sphere loop (sphere_seed)
-                        const float4 seed = ps.hit(kind)[slot];
+                        const float4 seed = STATS ? seedPre : ps.hit(kind)[slot];
                         best = seed.x; bestObj = __float_as_uint(seed.y); bestTri = 0;
                         plain = ray_is_plain(wo, wd);
                         reach = __float_as_uint(seed.z);
+                        earlyT = seed.w;
                         obj = 0; sp = 0;
                         if (PIX) { rayBox = 0; rayTri = 0; }
                         wt.totRays++;
@@ -861,6 +920,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
             }
         }
 
+        const unsigned long long tStep = STATS ? clock64() : 0ull;
         if (runI) {
             // ================= interior step: both children of the pair `cur` =================
             if (STATS) {
@@ -872,6 +932,26 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
             if ((int32_t)cur >= 0) {
                 float4 q0, q1, q2;
                 float2 lk;
+#if RT_HOT_AS
+                // The two sources are named by their address spaces. Left to itself the compiler merges the two branches into one
+                // set of loads through a generic pointer, i.e. FLAT instructions: those go through the vector memory pipeline even
+                // when the address is in LDS (the very pipeline the table is there to relieve), count in vmcnt and lgkmcnt alike
+                // and complete out of order, so every wait behind them is a wait for everything.
+                if (HOT && cur < min(sc.hotNodes, 2u * (uint32_t)HOT)) {
+                    // a child pair of a mesh's top levels: from the work-group's LDS copy (ds_read_b128 x 3 + ds_read_b64)
+                    const RT_AS_LDS rt_f4v* ph = (const RT_AS_LDS rt_f4v*)hotLds + 2 * cur;
+                    const rt_f4v a = ph[0], b = ph[1], c = ph[2];
+                    const rt_f2v l = *(const RT_AS_LDS rt_f2v*)(ph + 3);
+                    q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w);
+                    lk = make_float2(l.x, l.y);
+                } else {
+                    const RT_AS_GLOBAL rt_f4v* pr = (const RT_AS_GLOBAL rt_f4v*)sc.nodesPk + 2 * (size_t)cur;
+                    const rt_f4v a = pr[0], b = pr[1], c = pr[2];
+                    const rt_f2v l = *(const RT_AS_GLOBAL rt_f2v*)(pr + 3);
+                    q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w);
+                    lk = make_float2(l.x, l.y);
+                }
+#else
                 if (HOT && cur < min(sc.hotNodes, 2u * (uint32_t)HOT)) {
                     // a child pair of a mesh's top levels: from the work-group's LDS copy, not through the vector memory pipeline
                     const float4* ph = hotLds + 2 * cur;
@@ -882,6 +962,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     q0 = pr[0]; q1 = pr[1]; q2 = pr[2];
                     lk = *(const float2*)(pr + 3);
                 }
+#endif
+                if (STATS) RT_STAMP_AFTER_LOADS(wt.dbgLoad[2], tStep);
                 float d1, d2;
                 box_intersect_pair(q0, q1, q2, troXY, invXY, zOI, d1, d2);
                 if (PIX) rayBox += 2; else wt.totBox += 2;
@@ -905,12 +987,17 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
             const bool need = cur == RT_CUR_NEED;
             const bool has = sp > 0;
             uint32_t top;
+#if RT_PRELOAD_TOP
+            top = topPre;
+            if (OVF && need && sp > (uint32_t)STACK) top = ((const RT_AS_GLOBAL uint32_t*)ovf)[(sp - 1u - STACK) * ovfStride];
+#else
             if (OVF) {
                 top = stack[min((has ? sp : 1u) - 1u, (uint32_t)STACK) * RT_WAVE];
-                if (need && sp > (uint32_t)STACK) top = ovf[(sp - 1u - STACK) * ovfStride];
+                if (need && sp > (uint32_t)STACK) top = ((const RT_AS_GLOBAL uint32_t*)ovf)[(sp - 1u - STACK) * ovfStride];  // (named global: no FLAT load)
             } else {
                 top = stack[((has ? sp : 1u) - 1u) * RT_WAVE];
             }
+#endif
             const bool objLeft = obj < sc.objectCount;
             const bool ident = (nxFlags & 1u) && plain;  // identity transform: register moves only
             const uint32_t whenEmpty = objLeft ? (ident ? (atWorld ? nxW : RT_CUR_WORLD) : RT_CUR_SETUP) : RT_CUR_DONE;
@@ -967,12 +1054,15 @@ __global__ __launch_bounds__(RT_BLOCK, BLOCKS) void k_trace_pw(DevScene sc, Path
 
     if (STATS && lane_id() == 0) {
         const size_t w = (size_t)blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;
-        ta.waveTimes[2 * w] = tStart;
-        ta.waveTimes[2 * w + 1] = wall_clock64();
+        if (ta.waveTimes) {
+            ta.waveTimes[2 * w] = tStart;
+            ta.waveTimes[2 * w + 1] = wall_clock64();
+        }
         for (int k = 0; k < 4; k++) {
             atomicAdd(&ta.phaseStats[k], (unsigned long long)wt.dbgRounds[k]);
             atomicAdd(&ta.phaseStats[4 + k], (unsigned long long)wt.dbgLanes[k]);
             atomicAdd(&ta.phaseStats[8 + k], wt.dbgCycles[k]);
+            atomicAdd(&ta.phaseStats[16 + k], wt.dbgLoad[k]);
             if (k < 3) atomicAdd(&ta.phaseStats[12 + k], (unsigned long long)wt.dbgWait[k]);
         }
     }
@@ -1030,12 +1120,20 @@ __device__ __forceinline__ FullHit reconstruct_hit(const DevScene& sc, rt_vec3 r
         f.frontFace = h.frontFace;
         return f;
     }
-    const float4* inv = rt_global(sc.objInv) + 3 * obj;
-    float4 i0 = inv[0], i1 = inv[1], i2 = inv[2];
-    const float4* fwd = rt_global(sc.objFwd) + 3 * obj;
-    float4 m0 = fwd[0], m1 = fwd[1], m2 = fwd[2];
-    rt_vec3 trd = xform_dir_rows(i0, i1, i2, rd);
-    rt_vec3 tro = xform_point_rows(i0, i1, i2, ro);
+    // An object whose matrix and inverse are both exactly the identity (objMeta flag bit 3), hit by a plain ray: multiplying by
+    // the identity returns the operand bit for bit while every component is finite and none is -0 ((1 * x + 0 * y) + 0 * z: a -0
+    // would pick up the sign of 0 * y, an infinity would meet 0 * inf) — the condition the traversal's identity fast path tests on
+    // the ray (ray_is_plain, trace_wave) and that is tested here on the interpolated normal and the object-space hit point as
+    // well. Then neither matrix is fetched nor applied (Sponza: all 25 material groups; raytrace.comp:316-321).
+    const uint4 meta = rt_global(sc.objMeta)[obj];
+    const bool ident = RT_SHADE_IDENT && (meta.w & 8u) && ray_is_plain(ro, rd);
+    rt_vec3 trd = rd, tro = ro;
+    if (!ident) {
+        const float4* inv = rt_global(sc.objInv) + 3 * obj;
+        const float4 i0 = inv[0], i1 = inv[1], i2 = inv[2];
+        trd = xform_dir_rows(i0, i1, i2, rd);
+        tro = xform_point_rows(i0, i1, i2, ro);
+    }
     const float4* tp = rt_global(sc.triPos) + 3 * (size_t)tri;
     float4 a = tp[0], b = tp[1], c = tp[2];
     TriHit h = tri_intersect(tro, trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
@@ -1044,9 +1142,16 @@ __device__ __forceinline__ FullHit reconstruct_hit(const DevScene& sc, rt_vec3 r
     rt_vec3 ni = rt_add(rt_add(rt_scale(n0, h.w), rt_scale(n1, h.u)), rt_scale(n2, h.v));
     ni = rt_scale(ni, h.frontFace ? 1.f : -1.f);
     rt_vec3 op = rt_add(tro, rt_scale(trd, h.dst));
-    f.normal = rt_normalize(xform_dir_rows(m0, m1, m2, ni));
-    f.hitPoint = xform_point_rows(m0, m1, m2, op);
-    f.materialIndex = rt_global(sc.objMeta)[obj].z;
+    if (ident && vec_is_plain(ni) && vec_is_plain(op)) {
+        f.normal = rt_normalize(ni);
+        f.hitPoint = op;
+    } else {
+        const float4* fwd = rt_global(sc.objFwd) + 3 * obj;
+        const float4 m0 = fwd[0], m1 = fwd[1], m2 = fwd[2];
+        f.normal = rt_normalize(xform_dir_rows(m0, m1, m2, ni));
+        f.hitPoint = xform_point_rows(m0, m1, m2, op);
+    }
+    f.materialIndex = meta.z;
     f.frontFace = h.frontFace;
     return f;
 }
@@ -1149,19 +1254,22 @@ __device__ __forceinline__ void init_path(const DevScene& sc, const PathState& p
 }
 
 #define RT_QUEUE_HOLE 0xffffffffu   // queue entry without a path (multi-frame dispatch: the padding of a tile that is not a multiple of 64 slots)
-__global__ __launch_bounds__(RT_BLOCK) void k_raygen(DevScene sc, PathState ps, Queues q, FrameParams fp) {
-    uint32_t slot = blockIdx.x * RT_BLOCK + threadIdx.x;
+// slots [slotBegin, slotEnd) of the dispatch: one part of the multi-kernel pipeline (render_impl); the part's queues start with
+// its slots in order (position = slot - slotBegin)
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(DevScene sc, PathState ps, uint32_t* activeOut, uint32_t* raysOut, FrameParams fp,
+                                                     uint32_t slotBegin, uint32_t slotEnd) {
+    const uint32_t pos = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t slot = slotBegin + pos;
     // several frames per dispatch (rt_render_frames): the slots run over {64 tile slots} x {frames}, see FrameParams::nFrames
-    const uint32_t nSlots = fp.nFrames > 1u ? ((fp.nPixels + 63u) >> 6) * 64u * fp.nFrames : fp.nPixels;
-    if (slot >= nSlots) return;
+    if (slot >= slotEnd) return;
     if (fp.nFrames > 1u && slot_in_tile(fp, slot) >= fp.nPixels) {
-        q.active[0][slot] = RT_QUEUE_HOLE;
-        q.rays[0][slot] = RT_QUEUE_HOLE;
+        activeOut[pos] = RT_QUEUE_HOLE;
+        raysOut[pos] = RT_QUEUE_HOLE;
         return;
     }
     init_path(sc, ps, fp, slot);
-    q.active[0][slot] = slot;
-    q.rays[0][slot] = slot << 2;
+    activeOut[pos] = slot;
+    raysOut[pos] = slot << 2;
 }
 
 // ---------------------------------------------------------------- k_shade

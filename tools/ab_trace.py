@@ -18,7 +18,7 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--spp", type=int, default=2)
 ap.add_argument("--rounds", type=int, default=3)
-ap.add_argument("--phase-stats", action="store_true")
+ap.add_argument("--phase-stats", type=int, nargs="?", const=1, default=0, help="1: wave times of the last launch, 2 + k: of launch k")
 ap.add_argument("--bounce", type=int, default=8)
 ap.add_argument("--ntris", type=int, default=0, help="sponza stand-in triangle count (0 = default)")
 ap.add_argument("--row-stride", type=int, default=1, help="render only rows 0, s, 2s, ... (what rank 0 of s GPUs renders)")
@@ -36,7 +36,7 @@ pc = cam(W, H, singleRender=1, sampleLimit=args.spp, bounceLimit=args.bounce) if
 r = engine.Renderer(0)
 r.upload_scene(scene)
 if args.phase_stats:
-    r.set_tuning('phase_stats', 1)
+    r.set_tuning("phase_stats", args.phase_stats)
 variants = []
 for v in args.variants.split(";"):
     parts = v.split(",")

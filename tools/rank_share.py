@@ -7,17 +7,21 @@ from ray_tracer_amd import engine, scenes  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--spp", type=int, default=8)
+ap.add_argument("--tune", default="", help="comma-separated rt_set_tuning knobs")
+ap.add_argument("--worlds", default="1,2,4,8")
 args = ap.parse_args()
 W, H = 1920, 1080
 scene, label = scenes.CONFIGS["sponza"]()
 r = engine.Renderer(0)
+for kv in filter(None, args.tune.split(",")):
+    k, v = kv.split("="); r.set_tuning(k, int(v))
 r.upload_scene(scene)
 pc = scenes.sponza_camera(W, H, raysPerPixel=args.spp, progressive=1, singleRender=0)
 def groups(count, fif):
     k = (count + fif - 1) // fif
     return [count // k + (1 if j < count % k else 0) for j in range(k)]
 base = None
-for world in (1, 2, 4, 8):
+for world in [int(w) for w in args.worlds.split(',')]:
     tile = dict(row0=0, rowStride=world)
     for rep in range(2):   # the first pass warms up (ray cost, allocations)
         r.sync(); t = time.perf_counter(); i = 0
