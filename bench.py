@@ -12,10 +12,15 @@ value    = reference-semantics rays / s: 1 ray = 1 calculateIntersections call o
            segment). `unique_mrays_per_s` beside it counts only the scene queries the GPU actually executed (the
            duplicate NEE query merged, light queries answered from the emitter list not traced, the camera ray traced once per
            pixel and dispatch) — the roofline uses only executed work.
-roofline : achieved / frac = algorithmic bytes (32 B per box test + 36 B per triangle test + 100 B per reported hit, counted by
-           the kernel itself) / HIP-event time of the kernel's launches, against 8 TB/s; next to it what the PMC
-           counters of the same binary say (profiles/counters_*.json, stamped with a hash of the kernel sources): traffic and
-           hbm_counter_frac, TA busy, VALU issue, active lanes, L1 look-ups per ray.
+roofline : the dominant kernel (k_trace_pw) is bound by no bandwidth and no ALU: the counters of the HEAD binary (separate rocprofv3
+           --pmc passes, profiles/counters_*.json, stamped with a hash of the kernel sources) show its busiest unit to be the
+           vector-memory pipeline that serves its 16-byte gathers (texture addresser / L1 tag look-ups), with waves parked on
+           s_waitcnt more than half of their cycles. So: bound = that pipeline; achieved = L1 look-ups per second (look-ups per
+           executed ray from the counters x rays per second of kernel time, timed live with HIP events) x 16 B; peak = the gather
+           rate tools/gather_bench.hip measures on this chip (1.39 look-ups per clock and CU); frac = achieved / peak <= 1.
+           Beside it: algorithmic_gbps / algorithmic_frac (32 B per box test + 36 B per triangle test + 100 B per hit,
+           counted by the kernel, / launch time, against 8 TB/s — a cache-served rate that may exceed 1), traffic and
+           hbm_counter_frac (bytes that reach the fabric, PMC), ta_busy_frac, valu_issue_frac, wave_waiting_frac, active_lane_frac.
 cpu_baseline: the scalar oracle (oracle/, a port of the shader) timed on this host's cores on a bounded sample of the same frame;
 parity_check: those very rows rendered by the GPU and compared bit for bit (the oracle is the checker, never the product).
 """
@@ -29,6 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # see ray_tracer_amd.tiling.prepare_rccl_env (set before torch loads RCCL)
 
+
+GATHER_PEAK_LOOKUPS_PER_CLK_CU = 1.39   # tools/gather_bench.hip (profiles/README.md, "what a vector load costs")
 
 SCENE_NAMES = {"cornell": "Cornell", "bunny": "Cornell + bunny", "dragon": "Cornell + dragon", "sponza": "Sponza",
                "sponza_dragons": "Sponza + 16 dragon instances", "sponza_dragons_flat": "Sponza + 16 dragons (flattened)"}
@@ -45,6 +52,8 @@ def main():
     ap.add_argument("--spp", type=int, default=8, help="samples per pixel per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket traversal launches with HIP events")
+    ap.add_argument("--no-build", action="store_true", help="do not run __graft_entry__.build() first (under rocprofv3: build beforehand, so that no compiler or make process is started from the profiled one)")
+    ap.add_argument("--per-step-dispatches", type=int, default=5, help="after the timed region: this many steps dispatched one by one (one dispatch and, on N GPUs, one gather per step, as the reference's draw() loop presents every frame), reported as `per_step_dispatch`; 0 = skip")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, default); gloo only to rehearse N ranks on ONE GPU (strips gathered through host memory)")
     ap.add_argument("--tune", default="", help="comma-separated rt_set_tuning knobs, e.g. blocks_per_cu=2,refill=8")
@@ -70,7 +79,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    ge.build()  # mtime check under a file lock: one rank compiles if anything is stale, the others wait for it
+    if not args.no_build:
+        ge.build()  # mtime check under a file lock: one rank compiles if anything is stale, the others wait for it
     from ray_tracer_amd import engine, scenes, tiling
 
     rehearsal = args.backend == "gloo"
@@ -170,11 +180,39 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     trace_ms, trace_launches = r.trace_time_ms()
+    busy_ms = r.trace_busy_ms() if not args.no_profile else 0.0
     r.set_profiling(False)
     cnt = r.counters()
+    timed_pipeline = r.last_pipeline()   # of the timed region (the legs below may run in the other one)
+
+    # The same steps, one dispatch (and one gather) per step: what a host that presents every frame gets.
+    per_step = None
+    frames_rendered = args.warmup + args.steps   # progressive frames the image holds by now
+    if args.per_step_dispatches > 0:
+        k2 = args.per_step_dispatches
+        fif_saved, fif = fif, 1
+        run(args.warmup + args.steps, 1)   # untimed: the first dispatch of another shape (allocations, pipeline choice)
+        r.reset_counters()
+        fence()
+        t1 = time.perf_counter()
+        run(args.warmup + args.steps + 1, k2)
+        fence()
+        dt1 = time.perf_counter() - t1
+        c1 = r.counters()
+        fif = fif_saved
+        frames_rendered += 1 + k2
+        v1 = torch.tensor([float(c1["raysReference"]), float(c1["raysTraced"]), dt1], dtype=torch.float64, device=fdev)
+        if multi:
+            m1 = v1.clone()
+            dist.all_reduce(v1, op=dist.ReduceOp.SUM)
+            dist.all_reduce(m1, op=dist.ReduceOp.MAX)
+            dt1 = float(m1[2])
+        per_step = {"steps": k2, "ms_per_step": dt1 / k2 * 1e3, "value": float(v1[0]) / dt1 / 1e6, "unique_mrays_per_s": float(v1[1]) / dt1 / 1e6,
+                    "pipeline": ["multi-kernel", "fused"][r.last_pipeline()],
+                    "what": "one dispatch" + (" and one RCCL gather" if world > 1 else "") + " per step (frames_in_flight 1), outside the timed region"}
 
     keys = ["boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments"]
-    vec = torch.tensor([float(cnt[k]) for k in keys] + [dt, trace_ms, float(trace_launches)], dtype=torch.float64,
+    vec = torch.tensor([float(cnt[k]) for k in keys] + [dt, trace_ms, float(trace_launches), busy_ms], dtype=torch.float64,
                        device=fdev)
     if multi:
         mx = vec.clone()
@@ -182,12 +220,15 @@ def main():
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dt = float(mx[7])
     tot = {k: float(vec[i]) for i, k in enumerate(keys)}
-    sum_trace_ms, sum_launches = float(vec[8]), float(vec[9])
+    sum_trace_ms, sum_launches, sum_busy_ms = float(vec[8]), float(vec[9]), float(vec[10])
 
     if rank == 0:
         alg_bytes = 32.0 * tot["boxTests"] + 36.0 * tot["triTests"] + 100.0 * tot["raysHit"]
-        # per GPU: the kernel's algorithmic bytes per launch / its average launch duration
-        achieved = (alg_bytes / max(sum_launches, 1.0)) / ((sum_trace_ms / max(sum_launches, 1.0)) * 1e-3) / 1e9 if sum_trace_ms > 0 else None
+        launches = max(sum_launches, 1.0)
+        avg_launch_ms = sum_trace_ms / launches
+        # per GPU: the kernel's algorithmic bytes per launch / its average launch duration (SURVEY 8d)
+        alg_gbps = (alg_bytes / launches) / (avg_launch_ms * 1e-3) / 1e9 if sum_trace_ms > 0 else None
+        tkern = ["k_trace_pw", "k_render_fused"][timed_pipeline]
         out = {
             "metric": f"Mrays/s (reference-semantics closest-hit queries) at {W}x{H} {SCENE_NAMES[args.scene]}",
             "value": tot["raysReference"] / dt / 1e6,
@@ -199,46 +240,53 @@ def main():
             "config": {"workload": f"{args.scene} ({label}), {W}x{H}, {args.spp} spp/step, bounceLimit 8, "
                                    f"rows interleaved over {world} GPU(s)" + f", up to {fif} steps in flight per rank (groups of {'+'.join(map(str, groups(args.steps)))})" + (", one RCCL gather per group" if world > 1 else ""),
                        "scene": args.scene, "assets": label, "width": W, "height": H, "spp_per_step": args.spp, "frames_in_flight": fif,
-                       "pipeline": ["multi-kernel (k_trace_pw + k_shade per round)", "fused (k_render_fused)"][r.last_pipeline()]},
+                       "pipeline": ["multi-kernel (k_trace_pw + k_shade per round)", "fused (k_render_fused)"][timed_pipeline]},
             "unique_mrays_per_s": tot["raysTraced"] / dt / 1e6,
+            "value_counts": "calculateIntersections calls of the reference's shader (4 per diffuse segment); unique_mrays_per_s = scene queries the GPU executed",
             "spp_per_s": tot["paths"] / (W * H) / dt,
             "paths": tot["paths"], "segments": tot["segments"],
             "box_tests_per_ray": tot["boxTests"] / max(tot["raysTraced"], 1), "tri_tests_per_ray": tot["triTests"] / max(tot["raysTraced"], 1),
-            "roofline": {"bound": "hbm", "kernel": ["k_trace_pw", "k_render_fused (traversal + shading in one kernel)"][r.last_pipeline()], "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
-                         "achieved_is": "algorithmic bytes (32 B per box test + 36 B per triangle test + 100 B per hit, SURVEY 8d) per launch / launch time: a cache-served rate, see hbm_counter_frac for what reaches the fabric",
-                         "algorithmic_bytes_per_launch": alg_bytes / max(sum_launches, 1.0),
-                         "avg_launch_ms": sum_trace_ms / max(sum_launches, 1.0), "launches": sum_launches,
-                         "trace_share_of_step": (sum_trace_ms / world) / (dt * 1e3)},
         }
+        if per_step:
+            out["per_step_dispatch"] = per_step
+        # The kernel's roofline. `bound` names the unit the counters show busiest; achieved / peak / frac are the rate of that unit.
+        rf = {"kernel": tkern + ("" if tkern == "k_trace_pw" else " (traversal + shading in one kernel)"),
+              "bound": "vector-memory pipeline (16-byte gathers through the texture addresser and the L1 tags); latency- and divergence-limited: neither HBM nor MFMA nor VALU is near its peak",
+              "achieved": None, "peak": None, "unit": "GB/s", "frac": None, "traffic": None,
+              "achieved_is": "L1 look-ups per second x 16 B: look-ups per executed ray (PMC counters of the same binary) x executed rays / time with a traversal launch running (HIP events, live)",
+              "peak_is": "1.39 look-ups per clock and CU (tools/gather_bench.hip on this chip: a 64-lane dwordx4 gather costs the CU 46 clocks, L2-resident table) x 256 CUs x 2.4 GHz x 16 B",
+              "launches": sum_launches, "avg_launch_ms": avg_launch_ms,
+              "launch_overlap": sum_trace_ms / sum_busy_ms if sum_busy_ms > 0 else None,
+              "trace_busy_share_of_step": (sum_busy_ms / world) / (dt * 1e3) if sum_busy_ms > 0 else None,
+              "algorithmic_bytes_per_launch": alg_bytes / launches,
+              "algorithmic_gbps": alg_gbps, "algorithmic_frac": (alg_gbps / 8000.0) if alg_gbps else None,
+              "algorithmic_is": "SURVEY 8(d): 32 B per box test + 36 B per triangle test + 100 B per hit, counted by the kernel, per launch / average launch duration, against 8 TB/s of HBM. Mostly served by LDS / L1 / L2, so it can exceed 1: it says how much traversal work per second the kernel does, not how busy HBM is (hbm_counter_frac does). With the dispatch in parts on several streams the launches overlap (launch_overlap) and share the GPU, so a launch's duration is longer than the kernel would need alone"}
+        out["roofline"] = rf
         # What the hardware counters say about the same kernel: separate rocprofv3 --pmc passes of this very command
         # (tools/profile_round.sh -> profiles/), since PMC counters cannot be read from inside the process. The file is
         # stamped with a hash of the kernel sources; a stamp that no longer matches the tree is flagged, not hidden.
-        tkern = ["k_trace_pw", "k_render_fused"][r.last_pipeline()]
         cfile = os.path.join(ROOT, "profiles", f"counters_{tkern}_{args.scene}_{W}x{H}_{args.spp}spp.json")
-        rf = out["roofline"]
         if world == 1 and os.path.exists(cfile):
             with open(cfile) as f:
                 pm = json.load(f)
-            launch_s = rf["avg_launch_ms"] * 1e-3
-            rf["traffic"] = pm.get("traffic_bytes_per_launch")
             rf["counters_source"] = os.path.relpath(cfile, ROOT)
             rf["counters_stale"] = pm.get("source_sha") != kernel_source_sha()
-            if rf["traffic"] and launch_s > 0:
-                rf["hbm_counter_gbps"] = rf["traffic"] / launch_s / 1e9
+            rf["traffic"] = pm.get("traffic_bytes_per_launch")
+            if rf["traffic"] and pm.get("kernel_ms_under_profiler"):
+                # both from the profiled run (its own launch count and durations), per launch like everything else here
+                rf["hbm_counter_gbps"] = rf["traffic"] / (pm["kernel_ms_under_profiler"] * 1e-3) / 1e9
                 rf["hbm_counter_frac"] = rf["hbm_counter_gbps"] / 8000.0
-            for k in ("ta_busy_frac", "valu_issue_frac", "active_lane_frac", "wave_waiting_frac", "l1_lookups_per_ray",
-                      "effective_clock_ghz"):
+            for k in ("ta_busy_frac", "valu_issue_frac", "active_lane_frac", "wave_waiting_frac", "l1_lookups_per_ray", "effective_clock_ghz"):
                 if k in pm:
                     rf[k] = pm[k]
-            if "ta_busy_frac" in rf and "valu_issue_frac" in rf:
-                rf["bound_by_counters"] = (f"vector memory pipeline (TA busy {rf['ta_busy_frac'] * 100:.0f} %), then VALU issue ({rf['valu_issue_frac'] * 100:.0f} %), "
-                                           "not HBM: the algorithmic bytes are mostly served by L1 / L2 (traffic << algorithmic), see DESIGN.md section 6")
+            if pm.get("l1_lookups_per_ray") and sum_busy_ms > 0:
+                lookups_per_s = pm["l1_lookups_per_ray"] * tot["raysTraced"] / (sum_busy_ms * 1e-3)
+                rf["achieved"] = lookups_per_s * 16.0 / 1e9
+                rf["peak"] = GATHER_PEAK_LOOKUPS_PER_CLK_CU * 256 * 2.4e9 * 16.0 / 1e9
+                rf["frac"] = rf["achieved"] / rf["peak"]
         if world == 1:
-            # the nominal peak and a streaming copy measured on this very box (1 GiB, read + write), both quoted
-            out["roofline"]["measured_copy_gbps"] = r.copy_bandwidth_gbps(1 << 30, 5)
-            if achieved:
-                out["roofline"]["frac_of_measured_copy"] = achieved / out["roofline"]["measured_copy_gbps"]
+            # a streaming copy measured on this very box (1 GiB, read + write), next to the nominal 8 TB/s
+            rf["measured_copy_gbps"] = r.copy_bandwidth_gbps(1 << 30, 5)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"], ref_rows, tile = cpu_baseline(scene, pc, W, H, args)
             # the rows the oracle has just rendered are the rows of the bench frame at frameCount 0: render them on the
@@ -263,18 +311,18 @@ def main():
             # dispatched one by one: bit for bit, or the run fails
             r.reset_counters()
             solo = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
-            for i in range(args.warmup + args.steps):
+            for i in range(frames_rendered):
                 pc.frameCount = i
                 r.render(pc, W, H, out_ptr=solo.data_ptr(), sync=True)
             same = bool(torch.equal(solo.view(torch.int32), strip.view(torch.int32)))
-            out["in_flight_check"] = {"equal": same, "frames": args.warmup + args.steps,
+            out["in_flight_check"] = {"equal": same, "frames": frames_rendered,
                                       "what": "the progressive image after all steps, rendered in groups (steps in flight), equals the one rendered one dispatch per step"}
             del solo
         if args.check and multi:
             # the same frames rendered by one process must equal the stitched strips bit for bit
             r.reset_counters()
             solo = torch.zeros((H, W, 4), dtype=torch.float32, device=f"cuda:{local}")
-            for i in range(args.warmup + args.steps):
+            for i in range(frames_rendered):
                 pc.frameCount = i
                 r.render(pc, W, H, out_ptr=solo.data_ptr(), sync=True)
             same = bool(torch.equal(solo.cpu().view(torch.int32), frame.cpu().view(torch.int32)))

@@ -297,7 +297,13 @@ int  rt_update_objects(rt_ctx* ctx, const RenderObject* o, uint32_t n);
  * samples per pixel = singleRender ? sampleLimit : raysPerPixel (:570).
  * d_rgba: device pointer to nRows*width*4 floats (RGBA fp32, before any 8-bit
  * step), or NULL to use the ctx's own framebuffer (rt_read_rgba_f32).
- * Asynchronous on the ctx stream; rt_sync waits. */
+ * Asynchronous on the ctx stream; rt_sync waits. The call returns as soon as the dispatch is enqueued: the multi-kernel
+ * pipeline enqueues every round it can need (each kernel reads its queue length on the device and leaves at once when
+ * there is nothing left) in up to "lanes" parts on streams of their own, forked from and joined to the ctx stream, and
+ * never waits for the device (tests/test_async_contract.py: the host is held for less than a tenth of the dispatch's
+ * time on the bench frame in either pipeline). One exception: a context's first dispatch of >= 8 M pixel-samples of a
+ * scene whose ray cost it has not measured yet is preceded by a small blocking probe dispatch (a few ms, rt_ray_cost;
+ * "probe" 0 turns it off). */
 int  rt_render(rt_ctx* ctx, const PushConstants* pc, uint32_t width, uint32_t height,
                uint32_t row0, uint32_t rowStride, uint32_t nRows, float* d_rgba);
 /* nFrames consecutive progressive dispatches of the same tile — the same pixels, bit for bit, as nFrames calls of rt_render
@@ -331,6 +337,10 @@ int  rt_reset_counters(rt_ctx* ctx);
  * launch count since the last reset (synchronises). */
 int  rt_set_profiling(rt_ctx* ctx, int enabled);
 int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
+/* The time during which at least one bracketed traversal launch was running since profiling was switched on (the union
+ * of the launches' spans: a dispatch of the multi-kernel pipeline runs in parts on several streams, whose launches
+ * overlap, so the summed durations of rt_get_trace_time_ms can exceed the wall time). Synchronises. */
+int  rt_get_trace_busy_ms(rt_ctx* ctx, double* msOut);
 /* Performance knobs; none of them changes a pixel or a counter.
  *   "light_queries"  1 (default): the NEE ray and the cosine probe of a diffuse bounce, which only ask whether their
  *                    closest hit is emissive and how far it is (raytrace.comp:389-403,443-460), are answered from the list of
@@ -345,6 +355,12 @@ int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
  *   "fused_below_pixels"  paths of a dispatch (tile pixels x frames) below which -1 picks the fused pipeline
  *   "fused_below_box_tests"  ... and box tests per ray (measured on the context's earlier dispatches of
  *                    the scene, copied back without waiting) below which it does so at any size
+ *   "lanes"          multi-kernel pipeline: a dispatch of at least "lanes_min_kslots" x 1024 paths is rendered in this many
+ *                    independent parts (contiguous ranges of path slots, each with its own queues and its own stream, forked
+ *                    from and joined to the ctx stream), so that one part's shading kernel and the draining tail of its
+ *                    traversal launch run under the other parts' traversal; 1..4, default 3
+ *   "lane_grid_pct"  ... each part's traversal launch taking this share of the resident work-groups (default 50: three parts
+ *                    oversubscribe the GPU 1.5 times, so a part in its shading kernel leaves no traversal slot empty)
  *   "trace_variant"  0 = one ray per lane (k_trace), 1 = persistent waves (k_trace_pw)
  *   "refill", "mk_refill", "chunk", "w_setup", "w_leaf", "fast_lanes", "lds_stack", "blocks_per_cu",
  *   "tile_slots", "phase_stats": traversal scheduling details, see DESIGN.md
@@ -360,6 +376,10 @@ int  rt_get_trace_time_ms(rt_ctx* ctx, double* msOut, uint64_t* launchesOut);
  *                    launch so the blocks divide evenly over the resident waves ("batch_fixed" is
  *                    the fixed cost per block, in pixel units, that the chooser assumes) */
 int  rt_set_tuning(rt_ctx* ctx, const char* key, int value);
+/* The traversal kernel instantiation the last launch used, spelled as a demangler prints it ("k_trace_pw<20, false, false,
+ * false, false, 144, 5>", "k_render_fused<24, false, false, true>"): tests/test_instantiations.py forces every instantiation in
+ * the library and compares it with the oracle. The string lives in the context. */
+const char* rt_last_kernel(const rt_ctx* ctx);
 /* pipeline the last rt_render used (0 or 1) */
 int  rt_last_pipeline(const rt_ctx* ctx);
 /* box tests per executed ray of the uploaded scene as this context measured them (the figure the launch parameters

@@ -87,12 +87,15 @@ struct rt_ctx {
     size_t evUsed = 0;
     double traceMs = 0.0;
     uint64_t traceLaunches = 0;
+    hipEvent_t profBase = nullptr;                         // recorded when profiling is switched on: the origin of traceSpans
+    std::vector<std::pair<float, float>> traceSpans;       // [start, end) of every bracketed launch, ms since profBase (rt_get_trace_busy_ms)
     uint64_t traceLaunchesTotal = 0;
 
     // tuning (rt_set_tuning)
     int traceVariant = 1;   // 0 = one-ray-per-lane k_trace, 1 = persistent waves k_trace_pw
     int pipeline = -1;      // 0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline (k_render_fused), -1 = by tile size
     int lastPipeline = 0;   // what the last rt_render used
+    char lastKernel[96] = "";  // the traversal kernel instantiation of the last launch, as a demangler prints it (rt_last_kernel)
     uint32_t fusedBelowPixels = 4000000;  // auto: dispatches of fewer paths than this use the fused pipeline. Sponza, 8 spp, ms per step with 1 / 2 / 4 / 8
                                           // frames of 1080p in one dispatch: fused 117 / 113.5 / 111.3 / 110.2, multi-kernel 131.4 / 113.5 / 103.9 / 99.9
     uint32_t fusedBelowBoxTests = 90;     // auto: ... and so do scenes whose rays are short (box tests per ray, measured)
@@ -229,9 +232,12 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     int perCU = c->blocksPerCU;
     if (perCU <= 0) {
         hipError_t e;
-        if (hotMode == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false, CULL, HOT6, 6>, RT_BLOCK, 0);
-        else if (hotMode == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false, CULL, HOT5, 5>, RT_BLOCK, 0);
-        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false, CULL>, RT_BLOCK, 0);
+        e = hipErrorInvalidValue;
+        // (if constexpr: an instantiation the tables can never select is not compiled — every kernel in the library can be
+        // launched, and tests/test_instantiations.py launches every one of them against the oracle)
+        if constexpr (HOT6 > 0) { if (hotMode == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false, CULL, HOT6, 6>, RT_BLOCK, 0); }
+        if constexpr (HOT5 > 0) { if (hotMode == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false, CULL, HOT5, 5>, RT_BLOCK, 0); }
+        if (hotMode == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw<STACK, OVF, false, false, CULL>, RT_BLOCK, 0);
         if (e != hipSuccess || perCU <= 0) perCU = 4;
     }
     uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
@@ -256,8 +262,13 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     }
     TracePwArgs pa{ta.queue, ta.count, laneCounts + 4, (uint32_t)c->refillMk, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, (uint32_t)c->fastShare,
                    ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), waveTimes, overflow};
-    if (hotMode == 1) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL, HOT6, 6>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
-    else if (hotMode == 2) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL, HOT5, 5>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
+    {
+        const bool stats = hotMode == 0 && c->phaseStats, px = hotMode == 0 && (c->phaseStats || pix);
+        snprintf(c->lastKernel, sizeof c->lastKernel, "k_trace_pw<%d, %s, %s, %s, %s, %d, %d>", STACK, OVF ? "true" : "false", px ? "true" : "false",
+                 stats ? "true" : "false", CULL ? "true" : "false", hotMode == 1 ? HOT6 : hotMode == 2 ? HOT5 : 0, hotMode == 2 ? 5 : 6);
+    }
+    if (hotMode == 1) { if constexpr (HOT6 > 0) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL, HOT6, 6>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa); }
+    else if (hotMode == 2) { if constexpr (HOT5 > 0) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL, HOT5, 5>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa); }
     else if (c->phaseStats) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, true, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
     else if (pix) hipLaunchKernelGGL((k_trace_pw<STACK, OVF, true, false, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
     else hipLaunchKernelGGL((k_trace_pw<STACK, OVF, false, false, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
@@ -332,6 +343,7 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
     FusedArgs fa{c->q.counts + 5, fb, (DevCounters*)c->counterBuf.p, overflow, (uint32_t)c->refill, (uint32_t)c->wSetupFused, wLeaf, fastLanes, batchPixels, g, (uint32_t)c->fastShare, waveTimes, pixelRefill};
     c->lastBatchPixels = (int)batchPixels;
     const FusedKernArgs ka{c->sc, c->ps, fp, fa};
+    snprintf(c->lastKernel, sizeof c->lastKernel, "k_render_fused<%d, %s, %s, %s>", STACK, OVF ? "true" : "false", c->pixStats ? "true" : "false", CULL ? "true" : "false");
     if (c->pixStats) hipLaunchKernelGGL((k_render_fused<STACK, OVF, true, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
     else hipLaunchKernelGGL((k_render_fused<STACK, OVF, false, CULL>), dim3(blocks), dim3(RT_BLOCK), 0, c->stream, ka);
     RT_HIP(c, hipGetLastError());
@@ -375,6 +387,7 @@ int launch_fused(rt_ctx* c, const FrameParams& fp, float4* fb) {
 template <int STACK>
 void launch_v0_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     uint32_t blocks = (maxRays + RT_BLOCK - 1) / RT_BLOCK;
+    snprintf(c->lastKernel, sizeof c->lastKernel, "k_trace<%d>", STACK);
     hipLaunchKernelGGL((k_trace<STACK>), dim3(blocks), dim3(RT_BLOCK), 0, c->curStream ? c->curStream : c->stream, c->sc, c->ps, ta);
 }
 
@@ -437,6 +450,8 @@ int harvest_events(rt_ctx* c) {
         RT_HIP(c, hipEventElapsedTime(&ms, c->evPool[i].a, c->evPool[i].b));
         c->traceMs += ms;
         c->traceLaunches++;
+        float t0 = 0.f;
+        if (c->profBase && hipEventElapsedTime(&t0, c->profBase, c->evPool[i].a) == hipSuccess) c->traceSpans.emplace_back(t0, t0 + ms);
     }
     c->evUsed = 0;
     return 0;
@@ -543,6 +558,7 @@ void rt_destroy(rt_ctx* c) {
     if (c->snapEvent) (void)hipEventDestroy(c->snapEvent);
     if (c->pollEvent) (void)hipEventDestroy(c->pollEvent);
     if (c->forkEvent) (void)hipEventDestroy(c->forkEvent);
+    if (c->profBase) (void)hipEventDestroy(c->profBase);
     for (int l = 0; l < RT_MAX_LANES - 1; l++) {
         if (c->joinEvent[l]) (void)hipEventDestroy(c->joinEvent[l]);
         if (c->pollEventSide[l]) (void)hipEventDestroy(c->pollEventSide[l]);
@@ -1356,6 +1372,7 @@ int rt_reset_counters(rt_ctx* c) {
     c->snapBox = 0; c->snapRays = 0;
     int rc = harvest_events(c);
     c->traceMs = 0.0; c->traceLaunches = 0; c->traceLaunchesTotal = 0;
+    c->traceSpans.clear();
     return rc;
 }
 
@@ -1364,6 +1381,26 @@ int rt_set_profiling(rt_ctx* c, int on) {
     RT_HIP(c, hipStreamSynchronize(c->stream));
     int rc = harvest_events(c);
     c->profiling = on != 0;
+    if (on) {
+        if (!c->profBase) RT_HIP(c, hipEventCreate(&c->profBase));
+        RT_HIP(c, hipEventRecord(c->profBase, c->stream));
+        c->traceSpans.clear();
+    }
+    return rc;
+}
+
+int rt_get_trace_busy_ms(rt_ctx* c, double* ms) {
+    if (!c || !ms) return -1;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = harvest_events(c);
+    std::vector<std::pair<float, float>> v = c->traceSpans;
+    std::sort(v.begin(), v.end());
+    double busy = 0.0, end = -1e300;
+    for (const auto& iv : v) {
+        if ((double)iv.first > end) { busy += (double)iv.second - (double)iv.first; end = iv.second; }
+        else if ((double)iv.second > end) { busy += (double)iv.second - end; end = iv.second; }
+    }
+    *ms = busy;
     return rc;
 }
 
@@ -1375,6 +1412,8 @@ int rt_get_trace_time_ms(rt_ctx* c, double* ms, uint64_t* launches) {
     if (launches) *launches = c->traceLaunches;
     return rc;
 }
+
+const char* rt_last_kernel(const rt_ctx* c) { return c ? c->lastKernel : ""; }
 
 int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     if (!c || !key) return -1;

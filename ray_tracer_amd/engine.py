@@ -369,8 +369,18 @@ class Renderer:
         self._check(self._l.rt_get_trace_time_ms(self._h, C.byref(ms), C.byref(n)), "rt_get_trace_time_ms")
         return ms.value, n.value
 
+    def trace_busy_ms(self):
+        """Time during which at least one traversal launch ran (union of the launches' spans) since set_profiling(True)."""
+        ms = C.c_double()
+        self._check(self._l.rt_get_trace_busy_ms(self._h, C.byref(ms)), "rt_get_trace_busy_ms")
+        return ms.value
+
     def set_tuning(self, key, value):
         self._check(self._l.rt_set_tuning(self._h, key.encode(), int(value)), "rt_set_tuning")
+
+    def last_kernel(self):
+        """Traversal kernel instantiation of the last launch, e.g. 'k_trace_pw<20, false, false, false, false, 144, 5>'."""
+        return self._l.rt_last_kernel(self._h).decode()
 
     def last_pipeline(self):
         """0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline."""

@@ -1,0 +1,134 @@
+"""Every traversal kernel instantiation in the library, launched and compared with the oracle.
+
+The traversal is one device function (trace_wave) compiled into ~80 kernels: k_trace_pw<STACK, OVF, PIX, STATS, CULL, HOT, BLOCKS>,
+k_render_fused<STACK, OVF, PIX, CULL> and the one-ray-per-lane k_trace<STACK>. Which one runs follows from the scene (deepest
+leaf, placed objects), the dispatch (heat maps) and knobs — so the other parity tests cover whatever their scenes happen to
+select. Round 2 met a compiler pass (si-optimize-exec-masking-pre-ra, ROCm 7.2.0) that miscompiled ONE instantiation twice while
+all others stayed right, and the library has been built with that pass off since (__graft_entry__.HIPFLAGS). This test is the
+guard for that decision: it reads the list of instantiations out of the built library (host stubs in its symbol table), forces
+each of them through scenes of the right BVH depth, with and without placed objects, heat maps, phase statistics, the three
+top-level-table modes and the LDS stack caps, asks the library which kernel it launched (rt_last_kernel), compares pixels and
+counters with the oracle bit for bit, and fails if any instantiation in the binary was not reached."""
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from ray_tracer_amd import _capi, engine
+
+pytestmark = pytest.mark.gpu
+
+# the builder's depth cap is 64 and a mesh that deep cannot be made small; k_trace<64> is the A/B baseline kernel's last size
+UNREACHED_ON_PURPOSE = {"k_trace<64>"}
+
+
+def library_instantiations():
+    out = subprocess.run(["nm", "-C", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    return set(re.findall(r"__device_stub__(k_(?:trace_pw|render_fused|trace)<[^>]*>)", out))
+
+
+def _normals(tri):
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-20)
+    return np.repeat(n[:, None, :], 3, axis=1).astype(np.float32)
+
+
+def soup(n, seed, size=0.02):
+    """n small triangles scattered in the Cornell volume: a balanced BVH of depth ~ log2 n."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-0.6, 0.6, (n, 1, 3)).astype(np.float32)
+    c[:, :, 1] -= 0.4
+    tri = c + rng.uniform(-size, size, (n, 3, 3)).astype(np.float32)
+    return tri, _normals(tri)
+
+
+def skewed(n, p, seed):
+    """Centroids u**p: the binned builder keeps cutting a sparse tail off a dense corner, which gives a deep, lopsided tree."""
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(0, 1, (n, 1, 3))
+    c = (u ** p * 0.6).astype(np.float32)
+    c[:, :, 1] -= 0.5
+    tri = c + rng.uniform(-1e-4, 1e-4, (n, 3, 3)).astype(np.float32) * c.max(axis=2, keepdims=True).clip(1e-3)
+    tri = tri.astype(np.float32)
+    return tri, _normals(tri)
+
+
+# (name, mesh, depth bucket the mesh is made for)
+MESHES = [("d4", lambda: soup(24, 1, 0.08), (1, 8)), ("d13", lambda: soup(1200, 2, 0.04), (9, 16)), ("d17", lambda: soup(40000, 3), (17, 20)),
+          ("d22", lambda: soup(300000, 4, 0.01), (21, 24)), ("d28", lambda: skewed(100000, 4, 5), (25, 32)), ("d37", lambda: skewed(100000, 8, 6), (33, 48))]
+
+
+def build_scene(mesh, placed):
+    """The mesh under an identity placement, lit by the environment and a small emitter at the NEE rectangle; `placed`: two more
+    small meshes under general transforms, which is what makes the library pick its CULL kernels (rt_update_objects)."""
+    s = engine.Scene()
+    glow = s.add_material(engine.default_material(albedo=(0, 0, 0), emissionColor=(1, 0.9, 0.8), emissionStrength=3.0))
+    grey = s.add_material(engine.default_material(albedo=(0.7, 0.7, 0.75)))
+    mirror = s.add_material(engine.default_material(albedo=(1, 1, 1), reflectance=1.0))
+    tri, nrm = mesh()
+    s.add_mesh("main", tri, nrm, engine.placement(), grey)
+    depth = s.last_bvh_stats()["maxDepth"]
+    quad = np.array([[[-0.3, -1.5, -0.3], [0.3, -1.5, -0.3], [0.3, -1.5, 0.3]], [[-0.3, -1.5, -0.3], [0.3, -1.5, 0.3], [-0.3, -1.5, 0.3]]], np.float32)
+    s.add_mesh("light", quad, np.tile(np.array([0, 1, 0], np.float32), (2, 3, 1)), engine.placement(), glow)
+    floor = quad.copy() * 4
+    floor[:, :, 1] = 0.5
+    s.add_mesh("floor", floor, np.tile(np.array([0, -1, 0], np.float32), (2, 3, 1)), engine.placement(), grey)
+    if placed:
+        t2, n2 = soup(40, 77, 0.1)
+        s.add_mesh("placed_a", t2, n2, engine.placement(position=(0.5, 0.1, 0.2), rotation=(20, 35, 10), scale=(0.4, 0.5, 0.4)), mirror)
+        s.add_mesh("placed_b", t2, n2, engine.placement(position=(-0.5, 0.0, -0.1), rotation=(-15, 70, 5), scale=(0.5, 0.4, 0.6)), grey)
+    return s, depth
+
+
+def _same(img, cnt, ref, rc, what):
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), f"{what}: pixels differ from the oracle's"
+    for k in ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments", "emitterTests"):
+        assert cnt[k] == rc[k], f"{what}: counter {k}: gpu {cnt[k]} oracle {rc[k]}"
+    assert rc["lightQueryMismatch"] == 0
+
+
+def test_every_instantiation_in_the_library_against_the_oracle(renderer):
+    in_library = library_instantiations()
+    assert len(in_library) > 60, "could not read the kernel instantiations out of the library's symbol table"
+    reached = {}
+    W, H = 64, 48
+    knobs = ("pipeline", "hot_pairs", "lds_stack", "phase_stats", "trace_variant")
+    try:
+        for name, mesh, (lo, hi) in MESHES:
+            for placed in (False, True):
+                s, depth = build_scene(mesh, placed)
+                assert lo <= depth <= hi, f"mesh {name}: BVH depth {depth} left its bucket {lo}..{hi}"
+                pcs = {False: engine.push_constants(W, H, singleRender=1, sampleLimit=2, bounceLimit=4, environmentOn=True),
+                       True: engine.push_constants(W, H, singleRender=1, sampleLimit=2, bounceLimit=4, environmentOn=True, debug=2, boxCap=400, triangleCap=60)}
+                refs = {dbg: pyoracle.render(s, pc, W, H) for dbg, pc in pcs.items()}
+                renderer.upload_scene(s)
+
+                def run(tag, dbg=False, **tune):
+                    for k, v in tune.items():
+                        renderer.set_tuning(k, v)
+                    renderer.reset_counters()
+                    img = renderer.render(pcs[dbg], W, H)
+                    kern = renderer.last_kernel()
+                    _same(img, renderer.counters(), *refs[dbg], what=f"{name} placed={placed} {tag} -> {kern}")
+                    reached.setdefault(kern, f"{name} placed={placed} {tag}")
+                    for k in tune:
+                        renderer.set_tuning(k, {"pipeline": -1, "hot_pairs": 2, "lds_stack": 24, "phase_stats": 0, "trace_variant": 1}[k])
+
+                caps = [24] + ([16] if depth > 16 else []) + ([8] if depth > 8 else [])
+                for cap in caps:
+                    for hot in (0, 1, 2):
+                        run(f"multi-kernel hot_pairs={hot} lds_stack={cap}", pipeline=0, hot_pairs=hot, lds_stack=cap)
+                    run(f"multi-kernel heat map lds_stack={cap}", dbg=True, pipeline=0, lds_stack=cap)
+                    run(f"multi-kernel phase_stats lds_stack={cap}", pipeline=0, phase_stats=1, lds_stack=cap)
+                    run(f"fused lds_stack={cap}", pipeline=1, lds_stack=cap)
+                    run(f"fused heat map lds_stack={cap}", dbg=True, pipeline=1, lds_stack=cap)
+                run("one ray per lane", pipeline=0, trace_variant=0)
+    finally:
+        for k in knobs:
+            renderer.set_tuning(k, {"pipeline": -1, "hot_pairs": 2, "lds_stack": 24, "phase_stats": 0, "trace_variant": 1}[k])
+    unknown = set(reached) - in_library
+    assert not unknown, f"rt_last_kernel named kernels the library's symbol table does not hold: {sorted(unknown)}"
+    missed = in_library - set(reached) - UNREACHED_ON_PURPOSE
+    assert not missed, f"{len(missed)} instantiations in the library were never launched: {sorted(missed)}"

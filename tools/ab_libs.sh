@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 for pass in 1 2; do
   for n in $names; do
     lib=$PWD/ray_tracer_amd/librt_amd_$n.so; [ $n = head ] && lib=$PWD/ray_tracer_amd/librt_amd.so
-    RT_AMD_LIB=$lib timeout -k 10 300 python3 bench.py $args --cpu-seconds 0 --no-in-flight-check > gpurun_out/ab_$n.json 2> gpurun_out/ab_$n.err || { echo "$n failed"; tail -3 gpurun_out/ab_$n.err; exit 1; }
+    RT_AMD_LIB=$lib timeout -k 10 300 python3 bench.py $args --cpu-seconds 0 --no-in-flight-check --per-step-dispatches 0 > gpurun_out/ab_$n.json 2> gpurun_out/ab_$n.err || { echo "$n failed"; tail -3 gpurun_out/ab_$n.err; exit 1; }
     python3 - "$n" "$pass" <<'PY'
 import json, sys
 d = json.loads([l for l in open(f"gpurun_out/ab_{sys.argv[1]}.json") if l.startswith("{")][-1])

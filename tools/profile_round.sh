@@ -6,8 +6,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p $out
-CMD="python3 bench.py --steps 10 --warmup 10 --spp 8 --tune probe=0 $*"   # one warm-up group and one timed group of ten steps in flight (what the default bench.py run does twice); no ray-cost probe (its small launches would sit in the per-kernel averages; the warm-up measures the ray cost instead)
-timeout -k 10 400 $CMD > $out/bench.log 2>&1 || { tail -5 $out/bench.log; exit 1; }
+python3 -c 'import __graft_entry__ as g; g.build()' || exit 1   # before any profiled run: no compiler or make process is ever started under rocprofv3 (--no-build below)
+CMD="python3 bench.py --no-build --steps 10 --warmup 10 --spp 8 --tune probe=0 --per-step-dispatches 0 $*"   # one warm-up group and one timed group of ten steps in flight (what the default bench.py run does twice); no ray-cost probe (its small launches would sit in the per-kernel averages; the warm-up measures the ray cost instead)
+timeout -k 10 400 ${CMD/--per-step-dispatches 0/} > $out/bench.log 2>&1 || { tail -5 $out/bench.log; exit 1; }
 grep '^{' $out/bench.log | tail -1 > $out/bench.json
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $CMD --cpu-seconds 0 --no-in-flight-check > $out/bench_under_rocprof.log 2>&1 || { tail -5 $out/bench_under_rocprof.log; exit 1; }
 grep '^{' $out/bench_under_rocprof.log | tail -1 > $out/bench_under_rocprof.json
