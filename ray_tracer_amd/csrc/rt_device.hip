@@ -45,6 +45,8 @@ struct rt_ctx {
     DevScene sc{};
     std::vector<DevBuf> sceneBufs;
     DevBuf texelBuf, texInfoBuf, triUVBuf;
+    DevBuf objTreeBuf, objCostBuf;
+    int objTreeMin = 48;    // rt_set_tuning("object_tree_min"): general-transform objects from which the object hierarchy is built (0 = never)
     DevBuf matBuf, sphereBuf, sphereMatBuf, objInvBuf, objFwdBuf, objMetaBuf, objBoxBuf, objSkipBuf, maskBoxBuf, emitBuf, emitPreBuf;
     // host copies of what the emitter list is derived from (rebuild_emitters)
     std::vector<RayMaterial> hostMats;
@@ -547,7 +549,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->sceneBufs) dev_free(b);
-    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->emitBuf, &c->emitPreBuf, &c->texelBuf, &c->texInfoBuf, &c->triUVBuf, &c->stateBuf,
+    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->emitBuf, &c->emitPreBuf, &c->texelBuf, &c->texInfoBuf, &c->triUVBuf, &c->objTreeBuf, &c->objCostBuf, &c->stateBuf,
                       &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf, &c->waveTimeBuf, &c->probeBuf})
         dev_free(*b);
     (void)rt_comm_destroy(c);
@@ -760,6 +762,56 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
     }
     if ((rc = upload(c, c->objSkipBuf, skipCost.data(), skipCost.size() * sizeof(uint2)))) return rc;
     c->sc.objSkipCost = (const uint2*)c->objSkipBuf.p;
+    {   // the hierarchy over runs of general-transform objects with a padded box (rt_kernels.hip.h: DevScene::objTree), for scenes with
+        // many of them: measured on 256 separated bunny instances (tools/heuristics_table.py) against 7 % lost on C5's sixteen
+        // overlapping dragons, which stay below the threshold (and inside the rays' object masks anyway)
+        std::vector<float4> tree;
+        std::vector<uint2> cost((size_t)n + 1, make_uint2(0u, 0u));
+        for (uint32_t i = 0; i < n; i++) {
+            cost[i + 1] = cost[i];
+            if (meta[i].y == 0u) cost[i + 1].x += 2u; else cost[i + 1].y += meta[i].y;
+        }
+        uint32_t off[RT_OBJTREE_LEVELS + 1] = {};
+        uint32_t levels = 0;
+        if (c->objTreeMin > 0 && nGeneral >= (uint32_t)c->objTreeMin) {
+            auto skippable = [&](uint32_t i) { return i < n && (meta[i].w & 3u) == 2u; };
+            for (uint32_t k = 1; k <= (uint32_t)RT_OBJTREE_LEVELS; k++) {
+                off[k] = (uint32_t)(tree.size() / 2);
+                const uint32_t nb = (n + (1u << k) - 1) >> k;
+                for (uint32_t b = 0; b < nb; b++) {
+                    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                    bool ok = true;
+                    for (uint32_t i = b << k; i < ((b + 1) << k); i++) {
+                        if (!skippable(i)) { ok = false; break; }
+                        const float4 &l = wbox[2 * (size_t)i], &h = wbox[2 * (size_t)i + 1];
+                        lo[0] = std::min(lo[0], l.x); lo[1] = std::min(lo[1], l.y); lo[2] = std::min(lo[2], l.z);
+                        hi[0] = std::max(hi[0], h.x); hi[1] = std::max(hi[1], h.y); hi[2] = std::max(hi[2], h.z);
+                    }
+                    tree.push_back(ok ? make_float4(lo[0], lo[1], lo[2], 1.f) : make_float4(0.f, 0.f, 0.f, 0.f));
+                    tree.push_back(ok ? make_float4(hi[0], hi[1], hi[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f));
+                }
+            }
+            levels = (uint32_t)RT_OBJTREE_LEVELS;
+            if (getenv("RT_DEBUG_OBJTREE")) {
+                for (uint32_t k = 1; k <= levels; k++) {
+                    const uint32_t nb = (n + (1u << k) - 1) >> k;
+                    uint32_t valid = 0;
+                    for (uint32_t b = 0; b < nb; b++) valid += tree[2 * (size_t)(off[k] + b)].w != 0.f;
+                    const float4 &l = tree[2 * (size_t)(off[k] + std::min(1u, nb - 1))], &h = tree[2 * (size_t)(off[k] + std::min(1u, nb - 1)) + 1];
+                    fprintf(stderr, "[objtree] level %u: %u blocks, %u valid; block 1: (%g %g %g)-(%g %g %g)\n", k, nb, valid, l.x, l.y, l.z, h.x, h.y, h.z);
+                }
+                for (uint32_t i = 0; i < std::min(n, 6u); i++)
+                    fprintf(stderr, "[objtree] object %u flags %x box (%g %g %g)-(%g %g %g)\n", i, meta[i].w, wbox[2 * i].x, wbox[2 * i].y, wbox[2 * i].z, wbox[2 * i + 1].x, wbox[2 * i + 1].y, wbox[2 * i + 1].z);
+            }
+        }
+        if (tree.empty()) tree.assign(2, make_float4(0.f, 0.f, 0.f, 0.f));
+        if ((rc = upload(c, c->objTreeBuf, tree.data(), tree.size() * sizeof(float4)))) return rc;
+        if ((rc = upload(c, c->objCostBuf, cost.data(), cost.size() * sizeof(uint2)))) return rc;
+        c->sc.objTree = (const float4*)c->objTreeBuf.p;
+        c->sc.objCost = (const uint2*)c->objCostBuf.p;
+        for (int k = 0; k <= RT_OBJTREE_LEVELS; k++) c->sc.objTreeOff[k] = off[k];
+        c->sc.objTreeLevels = levels;
+    }
     c->sc.objInv = (const float4*)c->objInvBuf.p;
     c->sc.objFwd = (const float4*)c->objFwdBuf.p;
     c->sc.objMeta = (const uint4*)c->objMetaBuf.p;
@@ -1079,7 +1131,7 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
     DevScene sc = c->sc;
     sc.sphereCount = td.sphereCount;
     sc.objectCount = td.objectCount;
-    if (sc.objectCount < c->sc.objectCount) sc.reachCount = 0;  // a dispatch with fewer objects than were uploaded: no masks
+    if (sc.objectCount < c->sc.objectCount) { sc.reachCount = 0; sc.objTreeLevels = 0; }  // a dispatch with fewer objects than were uploaded: no masks, no object hierarchy
     // c->sc holds this dispatch's counts while the launches are built; whatever way the function is left, the uploaded scene comes back
     struct SceneGuard {
         rt_ctx* c; DevScene saved;
@@ -1332,7 +1384,7 @@ int rt_get_counters(rt_ctx* c, RtCounters* out) {
     out->traceLaunches = c->traceLaunchesTotal;
     out->emitterTests = h.emitterTests;
     if (c->phaseStats) {
-        unsigned long long ps[20];
+        unsigned long long ps[21];
         RT_HIP(c, hipMemcpy(ps, (char*)c->counterBuf.p + sizeof(DevCounters), sizeof(ps), hipMemcpyDeviceToHost));
         static const char* nm[4] = {"refill", "setup", "interior", "leaf"};
         for (int k = 0; k < 4; k++)
@@ -1341,6 +1393,7 @@ int rt_get_counters(rt_ctx* c, RtCounters* out) {
                     100.0 * ps[8 + k] / std::max(1.0, (double)(ps[8] + ps[9] + ps[10] + ps[11])));
         fprintf(stderr, "[phase_stats] clocks per round from the step's first load to its data: refill (queue entry, incl. the atomic) %.0f, setup (ray, seed) %.0f, interior (child pair) %.0f, leaf (triangles) %.0f\n",
                 ps[0] ? (double)ps[16] / ps[0] : 0.0, ps[1] ? (double)ps[17] / ps[1] : 0.0, ps[2] ? (double)ps[18] / ps[2] : 0.0, ps[3] ? (double)ps[19] / ps[3] : 0.0);
+        fprintf(stderr, "[phase_stats] trips of the set-up step's object-skipping loop: %llu (%.1f per lane and set-up step)\n", ps[20], ps[5] ? (double)ps[20] / ps[5] : 0.0);
         fprintf(stderr, "[phase_stats] lanes sitting out interior rounds: %.1f at a leaf, %.1f in set-up states, %.1f without a ray (of 64, average)\n",
                 ps[2] ? (double)ps[12] / ps[2] : 0.0, ps[2] ? (double)ps[13] / ps[2] : 0.0, ps[2] ? (double)ps[14] / ps[2] : 0.0);
         if (c->waveTimesCount && c->waveTimeBuf.p) {  // the last k_trace_pw launch: when did its waves finish?
@@ -1445,6 +1498,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "batch_pixels") { if (value < 0 || value > (int)RT_WAVE) return c->fail("batch_pixels must be 0 (auto) .. 64"); c->batchPixels = value; }
     else if (k == "batch_fixed") { if (value < 0 || value > 4096) return c->fail("batch_fixed out of range"); c->batchFixed = value; }
     else if (k == "phase_stats") { if (value < 0) return c->fail("phase_stats >= 0"); c->phaseStats = value; }
+    else if (k == "object_tree_min") { if (value < 0) return c->fail("object_tree_min >= 0"); c->objTreeMin = value; }
     else if (k == "lanes") { if (value < 1 || value > RT_MAX_LANES) return c->fail("lanes: 1..4 (parts of a multi-kernel dispatch, each on its own stream)"); c->lanes = value; }
     else if (k == "lane_grid_pct") { if (value < 10 || value > 100) return c->fail("lane_grid_pct: 10..100"); c->laneGridPct = value; }
     else if (k == "lanes_min_kslots") { if (value < 0) return c->fail("lanes_min_kslots >= 0"); c->lanesMinSlots = (uint32_t)value << 10; }

@@ -40,6 +40,9 @@
 #ifndef RT_TRI_X4
 #define RT_TRI_X4 1        // trace_wave, leaf step: a triangle's positions as three aligned dwordx4 loads
 #endif
+#ifndef RT_OBJTREE
+#define RT_OBJTREE 1       // trace_wave, set-up step: the object hierarchy's block jumps compiled in (CULL kernels)
+#endif
 #ifndef RT_SHADE_IDENT
 #define RT_SHADE_IDENT 1   // reconstruct_hit: no matrix loads / transforms for identity-transform objects hit by a plain ray
 #endif
@@ -47,6 +50,7 @@
 #define RT_LEAF_BIT 0x80000000u
 #define RT_HIT_NONE 0xffffffffu
 #define RT_HIT_SPHERE 0x80000000u
+#define RT_OBJTREE_LEVELS 8   // blocks of up to 256 objects in the object hierarchy (DevScene::objTree)
 
 // ---------------------------------------------------------------- scene in HBM
 // All arrays are read-only during a render.
@@ -92,6 +96,18 @@ struct DevScene {
     const float4* maskBox;   // reachCount x 2 float4: the objects a ray's creator tests for the ray's object mask (reach_mask_from)
     const uint2* objSkipCost; // 33 entries: {box tests, triangle tests} the reference spends on objects [maskBase, maskBase + i) when a ray misses them all
     uint32_t reachCount;     // entries of maskBox
+    // A hierarchy over the padded world boxes of consecutive general-transform objects, for scenes of many placed objects (the
+    // reference walks its objects linearly, raytrace.comp:289-350: two box tests per object a ray misses; 256 separated instances
+    // cost a ray 7 times the traversal of the same triangles in one mesh). Level k (1..objTreeLevels) holds, for every aligned
+    // block of 2^k objects that are all general-transform objects with a padded box, the union of their boxes ({lo.xyz, 1}{hi.xyz, -};
+    // w = 0: not such a block) at objTree[2 * (objTreeOff[k] + (object >> k))]. A ray that cannot reach a block's box before
+    // its closest hit cannot reach any object in it, so the set-up step's skipping loop jumps the whole block at the reference's
+    // cost for it (objCost: prefix sums over ALL objects of {box tests, triangle tests} a missed object is worth), in the
+    // reference's object order. objTreeLevels = 0: no hierarchy (few placed objects: rt_update_objects).
+    const float4* objTree;
+    const uint2* objCost;
+    uint32_t objTreeOff[RT_OBJTREE_LEVELS + 1];
+    uint32_t objTreeLevels;
     uint32_t maskBase;       // a ray's object mask covers objects [maskBase, maskBase + 32): the window starts at the first object that can be
                              // ruled out at all (C5: 26 identity-transform groups, then sixteen placed dragons — all sixteen inside the window)
     // Light queries (the NEE ray and the cosine probe of a diffuse bounce, raytrace.comp:443-453) only ask "is the closest hit
@@ -631,7 +647,7 @@ struct WaveTotals {
     uint32_t dbgRounds[4] = {0, 0, 0, 0}, dbgLanes[4] = {0, 0, 0, 0};  // refill, setup, interior, leaf (STATS)
     unsigned long long dbgCycles[4] = {0, 0, 0, 0};                    // shader clocks spent in rounds of each kind (STATS)
     unsigned long long dbgLoad[4] = {0, 0, 0, 0};                      // ... of which: from the step's first load instruction to the arrival of its data (STATS)
-    uint32_t dbgWait[3] = {0, 0, 0};  // STATS: lanes that sat out interior rounds at a leaf / in set-up states / without a ray
+    uint32_t dbgWait[4] = {0, 0, 0, 0};  // STATS: [3] trips of the set-up step's skipping loop; [0..2] lanes that sat out interior rounds at a leaf / in set-up states / without a ray
 };
 
 // OVF: the BVH is deeper than STACK; entries beyond the LDS part live in a global overflow buffer
@@ -879,6 +895,22 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         const rt_vec3 iw = rt_v3(1.f / wd.x, 1.f / wd.y, 1.f / wd.z);
                         // two objects per trip, their boxes fetched together (lo.w = objMeta flags, hi.w = root triangle count)
                         while (obj < sc.objectCount) {
+                            if (STATS) wt.dbgWait[2 + 1]++;   // (dbgWait[3]: trips of the skipping loop, summed over lanes)
+                            if (RT_OBJTREE && sc.objTreeLevels) {
+                                // the biggest aligned block of placed objects that starts here and is out of reach: jumped as a whole
+                                bool block = false;
+                                for (uint32_t k = obj ? min(sc.objTreeLevels, (uint32_t)__ffs((int)obj) - 1u) : sc.objTreeLevels; k >= 1u; k--) {
+                                    const float4* t = sc.objTree + 2 * (size_t)(sc.objTreeOff[k] + (obj >> k));
+                                    const float4 lo = t[0], hi = t[1];
+                                    if (lo.w == 0.f || box_intersect(lo, hi, wo, iw) < best) continue;  // not a block of placed objects, or reachable: its first half next
+                                    const uint2 c0 = sc.objCost[obj], c1 = sc.objCost[obj + (1u << k)];
+                                    if (PIX) { rayBox += c1.x - c0.x; rayTri += c1.y - c0.y; } else { wt.totBox += c1.x - c0.x; wt.totTri += c1.y - c0.y; }
+                                    obj += 1u << k;
+                                    block = true;
+                                    break;
+                                }
+                                if (block) continue;
+                            }
                             const uint32_t i1 = min(obj + 1u, sc.objectCount - 1u);
                             const float4 a0 = sc.objBox[2 * obj], b0 = sc.objBox[2 * obj + 1], a1 = sc.objBox[2 * i1], b1 = sc.objBox[2 * i1 + 1];
                             if ((__float_as_uint(a0.w) & 3u) != 2u) break;  // identity, or no usable box
@@ -888,6 +920,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                             else { if (PIX) rayTri += c0; else wt.totTri += c0; }
                             obj++;
                             if (obj >= sc.objectCount) break;
+                            if (RT_OBJTREE && sc.objTreeLevels && !(obj & 1u)) continue;  // an even index again: the blocks that start here come first
                             if ((__float_as_uint(a1.w) & 3u) != 2u) break;
                             if (box_intersect(a1, b1, wo, iw) < best) break;
                             const uint32_t c1 = __float_as_uint(b1.w);
@@ -1052,6 +1085,7 @@ __global__ __launch_bounds__(RT_BLOCK, BLOCKS) void k_trace_pw(DevScene sc, Path
     const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
     trace_wave<STACK, OVF, PIX, STATS, false, CULL, HOT>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt, s_meta, s_hot);
 
+    const uint32_t skipTrips = STATS ? wave_sum_u32(wt.dbgWait[3]) : 0u;
     if (STATS && lane_id() == 0) {
         const size_t w = (size_t)blockIdx.x * (RT_BLOCK / RT_WAVE) + threadIdx.x / RT_WAVE;
         if (ta.waveTimes) {
@@ -1064,6 +1098,7 @@ __global__ __launch_bounds__(RT_BLOCK, BLOCKS) void k_trace_pw(DevScene sc, Path
             atomicAdd(&ta.phaseStats[8 + k], wt.dbgCycles[k]);
             atomicAdd(&ta.phaseStats[16 + k], wt.dbgLoad[k]);
             if (k < 3) atomicAdd(&ta.phaseStats[12 + k], (unsigned long long)wt.dbgWait[k]);
+            else atomicAdd(&ta.phaseStats[20], (unsigned long long)skipTrips);
         }
     }
     unsigned long long wb = wave_sum_u64(wt.totBox), wtri = wave_sum_u64(wt.totTri);

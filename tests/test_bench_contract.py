@@ -24,11 +24,15 @@ def test_bench_line_has_the_contract_fields():
     assert d["unit"] == "Mrays/s" and d["value"] > 0 and d["ms_per_step"] > 0 and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["achieved"] > 0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+    # the kernel is bound by the vector-memory pipeline's gather rate, not by HBM: `frac` is that rate against the measured gather
+    # peak and cannot exceed 1; SURVEY 8(d)'s algorithmic rate (which can) and the HBM counters ride beside it under their own names
+    assert "vector-memory" in r["bound"] and r["unit"] == "GB/s" and r["peak"] > 8000.0 and r["achieved"] > 0
+    assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["algorithmic_gbps"] > 0 and abs(r["algorithmic_frac"] - r["algorithmic_gbps"] / 8000.0) < 1e-9 and "traffic" in r
+    assert d["per_step_dispatch"]["ms_per_step"] > 0 and d["unique_mrays_per_s"] > 0
     p = d["parity_check"]
     assert p["equal"] is True and p["max_rel"] == 0.0 and p["rows"] >= 4
-    assert d["in_flight_check"]["equal"] is True and d["in_flight_check"]["frames"] == 3
+    assert d["in_flight_check"]["equal"] is True and d["in_flight_check"]["frames"] == 3 + 1 + d["per_step_dispatch"]["steps"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
 

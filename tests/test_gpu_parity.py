@@ -584,6 +584,42 @@ def test_more_objects_than_the_object_mask_has_bits(renderer):
     _check(*_render_both(renderer, s, pc, W, H))
 
 
+@pytest.mark.parametrize("tree_min", [0, 2, 48])
+def test_object_hierarchy_over_many_placed_objects(renderer, tree_min):
+    """N2: the reference walks its objects linearly (raytrace.comp:289-350). From 48 placed objects on, the set-up step's skipping
+    loop jumps aligned blocks of 2..256 consecutive placed objects whose union box the ray cannot reach, at the reference's cost
+    for them, in the reference's order ("object_tree_min": 0 = never, 2 = already here). 150 objects: the Cornell box's nine, then
+    runs of placed meshes and leaf-root cards broken by identity-transform meshes (blocks must not straddle those), an emissive
+    one among them; pixels and every counter as the oracle's linear loop gives them."""
+    renderer.set_tuning("object_tree_min", tree_min)
+    try:
+        s = engine.Scene()
+        s.prepare_storage_buffers()
+        glow = s.add_material(engine.default_material(albedo=(0.9, 0.9, 0.3), emissionColor=(1.0, 0.9, 0.4), emissionStrength=2.0))
+        mats = [0, 1, 2, 4, 5, glow]
+        card = np.array([[[-0.05, 0, -0.05], [0.05, 0, -0.05], [0.05, 0, 0.05]], [[-0.05, 0, -0.05], [0.05, 0, 0.05], [-0.05, 0, 0.05]]], np.float32)
+        ncard = np.zeros_like(card); ncard[..., 1] = -1
+        blobs = [scenes.blob(60 + 10 * k, seed=200 + k, radius=1.0) for k in range(4)]
+        for k in range(141):
+            where = (-0.85 + 0.17 * (k % 11), -0.9 + 0.11 * (k // 11), -0.8 + 0.16 * (k % 9))
+            if k % 37 == 36:      # an identity-transform mesh breaks the run of placed objects
+                pos, nrm = scenes.blob(40, seed=300 + k, radius=0.05, center=where)
+                s.add_mesh(f"i{k}", pos, nrm, engine.placement(), mats[k % 6])
+            elif k % 5 == 4:
+                s.add_mesh(f"c{k}", card, ncard, engine.placement(position=where, rotation=(35 * k, 0, 20 * k)), mats[k % 6])
+            else:
+                pos, nrm = blobs[k % 4]
+                s.add_mesh(f"b{k % 4}", pos, nrm, engine.placement(position=where, scale=(0.04, 0.05, 0.035), rotation=(9 * k, 23 * k, 4 * k)), mats[k % 6])
+        assert s.counts()["objects"] == 150
+        W, H = 112, 84
+        pc = engine.push_constants(W, H, singleRender=1, sampleLimit=3, bounceLimit=6)
+        _check(*_render_both(renderer, s, pc, W, H))
+        pc = engine.push_constants(W, H, singleRender=1, sampleLimit=2, debug=2, boxCap=900, triangleCap=60)   # per-pixel counts through the heat map
+        _check(*_render_both(renderer, s, pc, W, H))
+    finally:
+        renderer.set_tuning("object_tree_min", 48)
+
+
 @pytest.mark.parametrize("n_identity,n_placed", [(34, 20), (3, 40), (31, 2)])
 def test_object_mask_window_starts_at_the_first_placed_object(renderer, n_identity, n_placed):
     """C5's shape: identity-transform groups first, placed (general-transform) objects after them. The 32 bits of a ray's
