@@ -211,19 +211,20 @@ def main():
                     "pipeline": ["multi-kernel", "fused"][r.last_pipeline()],
                     "what": "one dispatch" + (" and one RCCL gather" if world > 1 else "") + " per step (frames_in_flight 1), outside the timed region"}
 
-    keys = ["boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments"]
-    vec = torch.tensor([float(cnt[k]) for k in keys] + [dt, trace_ms, float(trace_launches), busy_ms], dtype=torch.float64,
+    keys = ["boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments", "skippedBoxTests"]
+    vec = torch.tensor([float(cnt[k]) for k in keys] + [dt, trace_ms, float(trace_launches), busy_ms], dtype=torch.float64,  # (the indices below follow len(keys))
                        device=fdev)
     if multi:
         mx = vec.clone()
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dt = float(mx[7])
+        dt = float(mx[len(keys)])
     tot = {k: float(vec[i]) for i, k in enumerate(keys)}
-    sum_trace_ms, sum_launches, sum_busy_ms = float(vec[8]), float(vec[9]), float(vec[10])
+    sum_trace_ms, sum_launches, sum_busy_ms = float(vec[len(keys) + 1]), float(vec[len(keys) + 2]), float(vec[len(keys) + 3])
 
     if rank == 0:
-        alg_bytes = 32.0 * tot["boxTests"] + 36.0 * tot["triTests"] + 100.0 * tot["raysHit"]
+        # executed tests only: what a ray is charged for objects it is taken past (two box tests each, never fetched) is left out
+        alg_bytes = 32.0 * (tot["boxTests"] - tot["skippedBoxTests"]) + 36.0 * tot["triTests"] + 100.0 * tot["raysHit"]
         launches = max(sum_launches, 1.0)
         avg_launch_ms = sum_trace_ms / launches
         # per GPU: the kernel's algorithmic bytes per launch / its average launch duration
@@ -246,6 +247,7 @@ def main():
             "spp_per_s": tot["paths"] / (W * H) / dt,
             "paths": tot["paths"], "segments": tot["segments"],
             "box_tests_per_ray": tot["boxTests"] / max(tot["raysTraced"], 1), "tri_tests_per_ray": tot["triTests"] / max(tot["raysTraced"], 1),
+            "executed_box_tests_per_ray": (tot["boxTests"] - tot["skippedBoxTests"]) / max(tot["raysTraced"], 1),
         }
         if per_step:
             out["per_step_dispatch"] = per_step
@@ -288,7 +290,7 @@ def main():
             # no counters of this workload in profiles/ (another scene, size or GPU count): the look-ups the traversal's own work
             # counters imply when none is served from LDS — four 16-byte loads per pair of child boxes, three per triangle, five per
             # ray (its record in, its hit out): an upper bound of the traversal's share, per GPU
-            est = 2.0 * tot["boxTests"] + 3.0 * tot["triTests"] + 5.0 * tot["raysTraced"]
+            est = 2.0 * (tot["boxTests"] - tot["skippedBoxTests"]) + 3.0 * tot["triTests"] + 5.0 * tot["raysTraced"]
             rf["achieved"] = est / (sum_busy_ms * 1e-3) / world * 16.0 / 1e9
             rf["achieved_from"] = "estimate from the kernel's work counters (2 look-ups per box test, 3 per triangle test, 5 per ray; upper bound: the top levels' pairs come from LDS)"
         if rf["achieved"] is not None:

@@ -246,6 +246,9 @@ typedef struct RtCounters {
     uint64_t segments;      /* path segments shaded */
     uint64_t traceLaunches; /* launches of the traversal kernel */
     uint64_t emitterTests;  /* emissive primitives tested directly by the creators of light queries (NEE ray, cosine probe) */
+    uint64_t skippedBoxTests; /* of boxTests: the two tests the reference makes on the children of an object's root, charged for objects
+                             * a ray was taken past without entering them (object masks, padded world boxes, the object hierarchy);
+                             * boxTests - skippedBoxTests were executed. 0 for scenes without placed objects */
 } RtCounters;
 
 /* One closest-hit record of calculateIntersections (raytrace.comp:276-353) */

@@ -87,7 +87,7 @@ class RtTexture(C.Structure):
 
 class RtCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference",
-                                          "paths", "segments", "traceLaunches", "emitterTests")]
+                                          "paths", "segments", "traceLaunches", "emitterTests", "skippedBoxTests")]
 
 
 class RtHit(C.Structure):

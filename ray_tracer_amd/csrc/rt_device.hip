@@ -100,7 +100,7 @@ struct rt_ctx {
     char lastKernel[96] = "";  // the traversal kernel instantiation of the last launch, as a demangler prints it (rt_last_kernel)
     uint32_t fusedBelowPixels = 4000000;  // auto: dispatches of fewer paths than this use the fused pipeline. Sponza, 8 spp, ms per step with 1 / 2 / 4 / 8
                                           // frames of 1080p in one dispatch: fused 117 / 113.5 / 111.3 / 110.2, multi-kernel 131.4 / 113.5 / 103.9 / 99.9
-    uint32_t fusedBelowBoxTests = 90;     // auto: ... and so do scenes whose rays are short (box tests per ray, measured)
+    uint32_t fusedBelowBoxTests = 70;     // auto: ... and so do scenes whose rays are short (box tests per ray, measured)
     // box tests per ray of this scene, from counter snapshots copied back asynchronously after each dispatch
     DevCounters* snap = nullptr;          // pinned
     hipEvent_t snapEvent = nullptr;
@@ -108,6 +108,8 @@ struct rt_ctx {
     bool snapPending = false;
     unsigned long long snapBox = 0, snapRays = 0;  // counters at the previous snapshot
     double boxPerRay = -1.0;              // < 0: not measured yet
+    double segPerPath = -1.0;             // path segments per pixel sample of this scene, from the same snapshots (< 0: not measured yet)
+    unsigned long long snapSeg = 0, snapPaths = 0;
     int refill = 8;         // k_trace_pw: idle lanes that trigger a refill
     int refillMk = 16;      // the same for k_trace_pw over the global queue (ten frames of the bench frame in flight: 8 -> 99.1, 16 -> 96.6, 24 -> 97.9, 32 -> 99.3 ms per step)
     int chunk = 256;        // k_trace_pw: most queue entries reserved per atomic
@@ -310,7 +312,11 @@ int launch_fused_t(rt_ctx* c, const FrameParams& fp, float4* fb) {
     // longer drains to its slowest pixel once per block) and when a wave gets fewer than five blocks (Cornell + bunny /
     // + dragon, rank 0's rows of 2 GPUs -3 %, of 4 GPUs -13 %); with short rays and many blocks per wave a block at a
     // time is 4-7 % faster (the full 1080p frame of Cornell, + bunny, + dragon)
-    const bool fewBlocks = ((uint64_t)nSlots + RT_WAVE - 1) / RT_WAVE < 5ull * resident * (RT_BLOCK / RT_WAVE);
+    // (scenes whose paths end early — open scenes, most samples leave after a bounce or two: fewer than 2.5 segments per sample
+    // against ~4 in a closed box — empty a block's lanes unevenly; there replacing pays up to eight blocks per wave:
+    // tools/heuristics_table.py, 256 bunnies on a floor under the sky, one 1080p frame: 19.1 against 19.7 ms)
+    const uint64_t fewBelow = (c->segPerPath >= 0.0 && c->segPerPath < 2.5) ? 8ull : 5ull;
+    const bool fewBlocks = ((uint64_t)nSlots + RT_WAVE - 1) / RT_WAVE < fewBelow * resident * (RT_BLOCK / RT_WAVE);
     const uint32_t pixelRefill = c->pixelRefill > 0 ? (uint32_t)c->pixelRefill
                                : ((c->boxPerRay >= (double)c->fusedBelowBoxTests || fewBlocks) ? 8u : (uint32_t)RT_WAVE);
     // a wave that replaces its pixels one by one evens out by itself as soon as there is more than one block per wave
@@ -1020,11 +1026,15 @@ namespace {
 void poll_ray_cost(rt_ctx* c) {
     if (!c->snapPending || hipEventQuery(c->snapEvent) != hipSuccess) return;
     c->snapPending = false;
-    const unsigned long long box = c->snap->boxTests, rays = c->snap->raysTraced;
+    const unsigned long long box = c->snap->boxTests - c->snap->skippedBoxTests, rays = c->snap->raysTraced;  // executed tests: what a ray costs the GPU
     if (rays > c->snapRays && box >= c->snapBox && rays - c->snapRays > 100000ull)
         c->boxPerRay = (double)(box - c->snapBox) / (double)(rays - c->snapRays);
+    const unsigned long long seg = c->snap->segments, paths = c->snap->paths;
+    if (paths > c->snapPaths && seg >= c->snapSeg && paths - c->snapPaths > 100000ull) c->segPerPath = (double)(seg - c->snapSeg) / (double)(paths - c->snapPaths);
     c->snapBox = box;
     c->snapRays = rays;
+    c->snapSeg = seg;
+    c->snapPaths = paths;
 }
 // Queue the next snapshot behind the dispatch just enqueued.
 void request_ray_cost(rt_ctx* c) {
@@ -1064,7 +1074,7 @@ int probe_ray_cost(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t 
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->snapPending = false;  // the probe's own snapshot request: its copy has arrived, and it is not wanted
     if (after.raysTraced > before.raysTraced + 1000ull)
-        c->boxPerRay = (double)(after.boxTests - before.boxTests) / (double)(after.raysTraced - before.raysTraced);
+        c->boxPerRay = (double)((after.boxTests - after.skippedBoxTests) - (before.boxTests - before.skippedBoxTests)) / (double)(after.raysTraced - before.raysTraced);
     return 0;
 }
 }  // namespace
@@ -1161,7 +1171,14 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
     double sizeLimit = (double)c->fusedBelowPixels;
     if (c->boxPerRay > 160.0) sizeLimit = std::max(0.5 * sizeLimit, sizeLimit - (c->boxPerRay - 160.0) * 38000.0);
     // (the paths of all the frames of the dispatch count: four frames of a quarter of a 4K frame are a 4K frame's worth)
-    c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (((double)nSlots < sizeLimit || shortRays) ? 1 : 0);
+    // Short rays keep the fused pipeline at any size — unless the traversal misses the caches: a scene whose hot data (child pairs
+    // and triangle positions) exceeds one XCD's 4 MB of L2 is bound by latency even with few tests per ray, and from 16 M paths the
+    // multi-kernel pipeline's extra resident waves and overlapping parts win there too (Cornell + bunny, 33 box tests per ray, ten
+    // 1080p frames: 36.4 against 38.7 ms per frame; + dragon 39.6 against 41.0), while small scenes (bobadog, the 45-object scene)
+    // and scenes of very short rays (fewer than 25 executed tests: 232 k loose triangles on a floor) stay fused (tools/heuristics_table.py)
+    const bool bigScene = (uint64_t)c->sc.nodeCount * 32u + (uint64_t)c->sc.triCount * 48u > (4ull << 20);
+    const bool shortButMissing = shortRays && bigScene && c->boxPerRay >= 25.0 && nSlots >= (16u << 20);
+    c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (((double)nSlots < sizeLimit || (shortRays && !shortButMissing)) ? 1 : 0);
     if (c->lastPipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch
         rc = launch_fused(c, fp, fb);
         if (!rc && nFrames > 1u) {
@@ -1383,6 +1400,7 @@ int rt_get_counters(rt_ctx* c, RtCounters* out) {
     out->raysReference = h.raysReference; out->paths = h.paths; out->segments = h.segments;
     out->traceLaunches = c->traceLaunchesTotal;
     out->emitterTests = h.emitterTests;
+    out->skippedBoxTests = h.skippedBoxTests;
     if (c->phaseStats) {
         unsigned long long ps[21];
         RT_HIP(c, hipMemcpy(ps, (char*)c->counterBuf.p + sizeof(DevCounters), sizeof(ps), hipMemcpyDeviceToHost));
@@ -1422,7 +1440,7 @@ int rt_reset_counters(rt_ctx* c) {
     RT_HIP(c, hipMemsetAsync(c->counterBuf.p, 0, sizeof(DevCounters) + 256, c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->snapPending = false;
-    c->snapBox = 0; c->snapRays = 0;
+    c->snapBox = 0; c->snapRays = 0; c->snapSeg = 0; c->snapPaths = 0;
     int rc = harvest_events(c);
     c->traceMs = 0.0; c->traceLaunches = 0; c->traceLaunchesTotal = 0;
     c->traceSpans.clear();

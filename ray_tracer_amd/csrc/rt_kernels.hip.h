@@ -194,6 +194,7 @@ struct FrameParams {
 
 struct DevCounters {
     unsigned long long boxTests, triTests, raysTraced, raysHit, raysReference, paths, segments, emitterTests;
+    unsigned long long skippedBoxTests;  // of boxTests: charged for objects rays were taken past (the reference tests the children of their roots), not executed
 };
 
 // ---------------------------------------------------------------- address spaces of the scene tables
@@ -644,6 +645,7 @@ struct TracePwArgs {
 // Counters a wave accumulates while it traces (reduced once per kernel).
 struct WaveTotals {
     uint32_t totBox = 0, totTri = 0, totRays = 0, totHits = 0;
+    uint32_t totSkipBox = 0;  // of totBox: box tests charged for objects the ray was taken past without entering them (CULL), not executed
     uint32_t dbgRounds[4] = {0, 0, 0, 0}, dbgLanes[4] = {0, 0, 0, 0};  // refill, setup, interior, leaf (STATS)
     unsigned long long dbgCycles[4] = {0, 0, 0, 0};                    // shader clocks spent in rounds of each kind (STATS)
     unsigned long long dbgLoad[4] = {0, 0, 0, 0};                      // ... of which: from the step's first load instruction to the arrival of its data (STATS)
@@ -703,6 +705,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
             if (skip) {
                 const uint2 c0 = sc.objSkipCost[w], c1 = sc.objSkipCost[w + skip];
                 if (PIX) { rayBox += c1.x - c0.x; rayTri += c1.y - c0.y; } else { wt.totBox += c1.x - c0.x; wt.totTri += c1.y - c0.y; }
+                wt.totSkipBox += c1.x - c0.x;
             }
             obj += skip;
         }
@@ -852,6 +855,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                             if (ahead) {
                                 const uint2 c0 = sc.objSkipCost[obj - sc.maskBase - ahead], c1 = sc.objSkipCost[obj - sc.maskBase];
                                 if (PIX) { rayBox -= c1.x - c0.x; rayTri -= c1.y - c0.y; } else { wt.totBox -= c1.x - c0.x; wt.totTri -= c1.y - c0.y; }
+                                wt.totSkipBox -= c1.x - c0.x;
                             }
                         }
                         best = RT_MISS_DST; bestObj = RT_HIT_NONE; bestTri = 0;
@@ -905,6 +909,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                                     if (lo.w == 0.f || box_intersect(lo, hi, wo, iw) < best) continue;  // not a block of placed objects, or reachable: its first half next
                                     const uint2 c0 = sc.objCost[obj], c1 = sc.objCost[obj + (1u << k)];
                                     if (PIX) { rayBox += c1.x - c0.x; rayTri += c1.y - c0.y; } else { wt.totBox += c1.x - c0.x; wt.totTri += c1.y - c0.y; }
+                                    wt.totSkipBox += c1.x - c0.x;
                                     obj += 1u << k;
                                     block = true;
                                     break;
@@ -916,7 +921,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                             if ((__float_as_uint(a0.w) & 3u) != 2u) break;  // identity, or no usable box
                             if (box_intersect(a0, b0, wo, iw) < best) break;
                             const uint32_t c0 = __float_as_uint(b0.w);
-                            if (c0 == 0u) { if (PIX) rayBox += 2; else wt.totBox += 2; }
+                            if (c0 == 0u) { if (PIX) rayBox += 2; else wt.totBox += 2; wt.totSkipBox += 2; }
                             else { if (PIX) rayTri += c0; else wt.totTri += c0; }
                             obj++;
                             if (obj >= sc.objectCount) break;
@@ -924,7 +929,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                             if ((__float_as_uint(a1.w) & 3u) != 2u) break;
                             if (box_intersect(a1, b1, wo, iw) < best) break;
                             const uint32_t c1 = __float_as_uint(b1.w);
-                            if (c1 == 0u) { if (PIX) rayBox += 2; else wt.totBox += 2; }
+                            if (c1 == 0u) { if (PIX) rayBox += 2; else wt.totBox += 2; wt.totSkipBox += 2; }
                             else { if (PIX) rayTri += c1; else wt.totTri += c1; }
                             obj++;
                         }
@@ -1103,7 +1108,9 @@ __global__ __launch_bounds__(RT_BLOCK, BLOCKS) void k_trace_pw(DevScene sc, Path
     }
     unsigned long long wb = wave_sum_u64(wt.totBox), wtri = wave_sum_u64(wt.totTri);
     uint32_t wr = wave_sum_u32(wt.totRays), wh = wave_sum_u32(wt.totHits);
+    const unsigned long long wskip = CULL ? wave_sum_u64(wt.totSkipBox) : 0ull;
     if (lane_id() == 0 && wr) {
+        if (CULL && wskip) atomicAdd(&ta.counters->skippedBoxTests, wskip);
         atomicAdd(&ta.counters->boxTests, wb);
         atomicAdd(&ta.counters->triTests, wtri);
         atomicAdd(&ta.counters->raysTraced, (unsigned long long)wr);
@@ -1836,7 +1843,9 @@ __global__ __launch_bounds__(RT_BLOCK, 5) void k_render_fused(FusedKernArgs ka) 
     unsigned long long wb = wave_sum_u64(wt.totBox), wtri = wave_sum_u64(wt.totTri);
     uint32_t wr = wave_sum_u32(wt.totRays), wh = wave_sum_u32(wt.totHits);
     uint32_t wRef = wave_sum_u32(refTot), wP = wave_sum_u32(pathTot), wS = wave_sum_u32(segTot), wE = wave_sum_u32(emitTot);
+    const unsigned long long wskip = CULL ? wave_sum_u64(wt.totSkipBox) : 0ull;
     if (lane_id() == 0 && (wr | wP | wS)) {
+        if (CULL && wskip) atomicAdd(&fa.counters->skippedBoxTests, wskip);
         if (wE) atomicAdd(&fa.counters->emitterTests, (unsigned long long)wE);
         atomicAdd(&fa.counters->boxTests, wb);
         atomicAdd(&fa.counters->triTests, wtri);

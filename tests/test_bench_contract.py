@@ -68,3 +68,13 @@ def test_four_rank_rehearsal_on_one_gpu_stitches_the_single_process_frame():
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["check_tiled_equals_single"] is True
     assert d["n_gpus"] == 4 and d["steps"] == 7 and d["config"]["frames_in_flight"] == 4 and d["value"] > 0
+
+
+def test_scripts_parse():
+    """bench.py, __graft_entry__.py and the tools compile (CPU): a syntax slip in one of them must not wait for the GPU box to show."""
+    import glob
+    import py_compile
+    for f in [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + glob.glob(os.path.join(ROOT, "tools", "*.py")):
+        py_compile.compile(f, doraise=True)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert p.returncode == 0 and "--per-step-dispatches" in p.stdout

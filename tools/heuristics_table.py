@@ -102,7 +102,14 @@ def bunnies256_flat():
     return s, cam
 
 
-SCENES = {"klein8": klein8, "bobadog": bobadog, "objects45": objects45, "bunnies256": bunnies256, "bunnies256_flat": bunnies256_flat}
+def _config(key):
+    def make():
+        s, _ = scenes.CONFIGS[key]()
+        return s, (scenes.sponza_camera if key.startswith("sponza") else engine.push_constants)
+    return make
+
+
+SCENES = {**{k: _config(k) for k in scenes.CONFIGS}, "klein8": klein8, "bobadog": bobadog, "objects45": objects45, "bunnies256": bunnies256, "bunnies256_flat": bunnies256_flat}
 
 
 def main():
