@@ -95,6 +95,7 @@ def test_every_instantiation_in_the_library_against_the_oracle(renderer):
     reached = {}
     W, H = 64, 48
     knobs = ("pipeline", "hot_pairs", "lds_stack", "phase_stats", "trace_variant")
+    renderer.set_tuning("blocks_per_cu", 0); renderer.set_tuning("pixel_refill", 0)
     try:
         for name, mesh, (lo, hi) in MESHES:
             for placed in (False, True):
@@ -115,6 +116,21 @@ def test_every_instantiation_in_the_library_against_the_oracle(renderer):
                     reached.setdefault(kern, f"{name} placed={placed} {tag}")
                     for k in tune:
                         renderer.set_tuning(k, {"pipeline": -1, "hot_pairs": 2, "lds_stack": 24, "phase_stats": 0, "trace_variant": 1}[k])
+
+                # the fused kernel once more on a tile big enough that a wave works through several blocks and replaces finished pixels
+                # while its other lanes are in flight (one work-group per CU, pixels replaced at 8 free lanes): round 3's wrong binary
+                # of k_render_fused<24, true, false, false> was right on one block per wave and wrong from the second hand-out on
+                if True:
+                    Wb, Hb = 512, 384
+                    pcb = engine.push_constants(Wb, Hb, singleRender=1, sampleLimit=2, bounceLimit=4, environmentOn=True)
+                    refb = pyoracle.render(s, pcb, Wb, Hb, threads=pyoracle.effective_cpus())
+                    for k, v in (("pipeline", 1), ("blocks_per_cu", 1), ("pixel_refill", 8)):
+                        renderer.set_tuning(k, v)
+                    renderer.reset_counters()
+                    imgb = renderer.render(pcb, Wb, Hb)
+                    _same(imgb, renderer.counters(), *refb, what=f"{name} placed={placed} fused, several blocks per wave -> {renderer.last_kernel()}")
+                    for k, v in (("pipeline", -1), ("blocks_per_cu", 0), ("pixel_refill", 0)):
+                        renderer.set_tuning(k, v)
 
                 caps = [24] + ([16] if depth > 16 else []) + ([8] if depth > 8 else [])
                 for cap in caps:

@@ -13,7 +13,7 @@ for pass in 1 2; do
 import json, sys
 d = json.loads([l for l in open(f"gpurun_out/ab_{sys.argv[1]}.json") if l.startswith("{")][-1])
 r = d["roofline"]
-print(f"pass {sys.argv[2]} {sys.argv[1]:10s} {d['ms_per_step']:8.2f} ms/step  {d['value']:8.1f} Mrays/s  trace {r['avg_launch_ms']:.3f} ms x {r['launches']:.0f}  share {r['trace_share_of_step']:.3f}", flush=True)
+print(f"pass {sys.argv[2]} {sys.argv[1]:10s} {d['ms_per_step']:8.2f} ms/step  {d['value']:8.1f} Mrays/s  trace {r['avg_launch_ms']:.3f} ms x {r['launches']:.0f}", flush=True)
 PY
   done
 done
