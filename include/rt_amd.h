@@ -417,6 +417,10 @@ int  rt_comm_destroy(rt_ctx* ctx);
 /* d_strip: this rank's rows rank, rank + N, ... of a width x height RGBA fp32 frame, in that order (what rt_render wrote);
  * d_frame: the whole frame, on `root` only (NULL elsewhere). Every rank of the communicator must call it. */
 int  rt_gather_strips(rt_ctx* ctx, const float* d_strip, uint32_t width, uint32_t height, int root, float* d_frame);
+/* The second half of rt_gather_strips on its own, for a host that moves the strips by other means: d_strips holds the strips
+ * of ranks 0 .. nRanks - 1 one after the other (rank r: its ceil((height - r) / nRanks) rows in order), d_frame receives the
+ * frame's rows. Asynchronous on the ctx stream. (tests: the row arithmetic for heights that nRanks does not divide) */
+int  rt_deinterleave_strips(rt_ctx* ctx, const float* d_strips, uint32_t width, uint32_t height, int nRanks, float* d_frame);
 
 /* device self-test of the deterministic-math build (must equal RT_SELFTEST_EXPECT) */
 int  rt_device_selftest(rt_ctx* ctx, uint32_t* bitsOut);

@@ -1800,11 +1800,19 @@ int rt_gather_strips(rt_ctx* c, const float* d_strip, uint32_t width, uint32_t h
     if (r != ncclSuccess) return rccl_fail(c, r, "ncclSend/ncclRecv");
     if (e != ncclSuccess) return rccl_fail(c, e, "ncclGroupEnd");
     if (me == root) {  // strips (rank-major) -> image rows: row y came from rank y % N, its row y / N
-        const size_t n4 = (size_t)height * width;
-        hipLaunchKernelGGL(k_deinterleave_rows, dim3((unsigned)((n4 + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, c->stream,
-                           (const float4*)stage, (float4*)d_frame, width, height, (uint32_t)N);
-        RT_HIP(c, hipGetLastError());
+        return rt_deinterleave_strips(c, stage, width, height, N, d_frame);
     }
+    return 0;
+}
+
+int rt_deinterleave_strips(rt_ctx* c, const float* d_strips, uint32_t width, uint32_t height, int nRanks, float* d_frame) {
+    if (!c || !d_strips || !d_frame) return -1;
+    if (nRanks < 1 || width == 0 || height == 0) return c->fail("rt_deinterleave_strips: bad geometry");
+    RT_HIP(c, hipSetDevice(c->device));
+    const size_t n4 = (size_t)height * width;
+    hipLaunchKernelGGL(k_deinterleave_rows, dim3((unsigned)((n4 + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, c->stream,
+                       (const float4*)d_strips, (float4*)d_frame, width, height, (uint32_t)nRanks);
+    RT_HIP(c, hipGetLastError());
     return 0;
 }
 

@@ -418,6 +418,11 @@ class Renderer:
         self._check(self._l.rt_gather_strips(self._h, C.c_void_p(strip_ptr), width, height, int(root),
                                              C.c_void_p(frame_ptr) if frame_ptr else None), "rt_gather_strips")
 
+    def deinterleave_strips(self, strips_ptr, width, height, n_ranks, frame_ptr):
+        """Strips of ranks 0..n_ranks-1 stored one after the other (device pointer) -> the frame's rows (device pointer)."""
+        self._check(self._l.rt_deinterleave_strips(self._h, C.c_void_p(strips_ptr), width, height, int(n_ranks), C.c_void_p(frame_ptr)),
+                    "rt_deinterleave_strips")
+
     def math_probe(self, inputs):
         """include/rt_probe.h evaluated on the device: [n, 32] float32 -> [n, 64] float32."""
         x = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 32)

@@ -50,6 +50,11 @@ def build_parser():
     ap.add_argument("--obj-rotation", type=float, nargs=3, default=(0.0, 0.0, 0.0))
     ap.add_argument("--obj-albedo-map", help="with --scene obj: an image bound as the albedo texture of the OBJ's materials "
                                              "(what an MTL's map_Kd line does; dread.mtl has none, the author bound dread_alb.png by hand)")
+    ap.add_argument("--textures", action="store_true",
+                    help="sample the maps the scene's MTL files name (and --obj-albedo-map). Off by default: the reference snapshot uploads "
+                         "textures and never samples them (raytrace.comp declares TextureBuffer / TextureSampler and reads neither), so the "
+                         "untextured image is the one that matches its shader; the sampling semantics are this build's declaration "
+                         "(DESIGN.md 3a, parity unpinned)")
     ap.add_argument("--width", type=int, default=1728)
     ap.add_argument("--height", type=int, default=1117)
     ap.add_argument("--device", type=int, default=0, help="GPU of a single-process run (one process per GPU uses LOCAL_RANK)")
@@ -151,8 +156,12 @@ def main(argv=None):
     r = engine.Renderer(device)
     r.upload_scene(scene)
     paths = scene.texture_paths()
-    if paths and all(os.path.exists(p) for p in paths):   # the MTL files' maps (src/vk_engine.cpp:1155); absent files: untextured
+    textured = False
+    if args.textures and paths and all(os.path.exists(p) for p in paths):   # the MTL files' maps (src/vk_engine.cpp:1155); absent files: untextured
         r.upload_textures(engine.load_textures(scene))
+        textured = True
+    elif paths and rank == 0:
+        print(f"{len(paths)} texture map(s) named by the scene are not sampled (the reference's shader samples none; --textures applies this build's declared semantics)")
     W, H = args.width, args.height
     tile = dict(row0=rank, rowStride=world) if world > 1 else {}
     t0 = time.perf_counter()
@@ -180,7 +189,7 @@ def main(argv=None):
         dist.all_reduce(tot)
         c = {"raysReference": float(tot[0]), "raysTraced": float(tot[1])}
     if rank == 0:
-        print(f"{label}: {W}x{H}, {r.totalSamples} spp in {frames} dispatch(es)" + (f" on {world} GPUs" if world > 1 else "") +
+        print(f"{label}{' [textures sampled: declared semantics, parity unpinned]' if textured else ''}: {W}x{H}, {r.totalSamples} spp in {frames} dispatch(es)" + (f" on {world} GPUs" if world > 1 else "") +
               f", {dt:.3f} s, {c['raysReference'] / dt / 1e6:.0f} Mrays/s (reference semantics), {c['raysTraced'] / dt / 1e6:.0f} M executed rays/s")
         if args.out and img is not None:
             if args.out.endswith(".npy"):

@@ -87,3 +87,23 @@ def test_cpp_host_follows_integration_md(tmp_path, renderer):
     assert np.array_equal(frames[0].view(np.uint32), a.view(np.uint32))
     assert np.array_equal(frames[1].view(np.uint32), b.view(np.uint32))
     assert not np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ranks,height", [(1, 5), (2, 7), (3, 10), (3, 2), (8, 1080), (8, 1083), (5, 3)])
+def test_strips_of_n_ranks_become_the_frame(renderer, n_ranks, height):
+    """rt_gather_strips' second half (k_deinterleave_rows) with more than one rank's strips, heights the rank count does not divide
+    and fewer rows than ranks: rank r's strip holds rows r, r + N, ... and the strips lie rank after rank (the RCCL
+    gather itself has only ever run with one rank, where this step is the identity)."""
+    import numpy as np
+    import torch
+    width = 37
+    frame = np.arange(height * width * 4, dtype=np.float32).reshape(height, width, 4)
+    strips = np.concatenate([frame[r::n_ranks] for r in range(n_ranks)], axis=0)
+    assert strips.shape == frame.shape
+    d_strips = torch.from_numpy(strips).cuda()
+    d_frame = torch.full((height, width, 4), -1.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    renderer.deinterleave_strips(d_strips.data_ptr(), width, height, n_ranks, d_frame.data_ptr())
+    renderer.sync()
+    assert np.array_equal(d_frame.cpu().numpy(), frame)

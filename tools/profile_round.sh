@@ -18,7 +18,10 @@ kern=$(python3 -c "import json; print('k_render_fused' if 'fused' in json.load(o
 i=0
 for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY" "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_FLAT_READ_WAVEFRONTS_sum"; do
   i=$((i+1))
-  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc/pass_$i -- $CMD --cpu-seconds 0 --no-in-flight-check > $out/pmc_$i.log 2>&1 || { echo "pmc pass $i ($set) failed"; tail -5 $out/pmc_$i.log; }
+  # counter passes: the dispatch in ONE part ("lanes" 1). rocprofv3 serialises kernels while it collects counters, so the three
+  # overlapping parts of a normal dispatch would each be measured alone on their half-size grids; one part is the kernel alone
+  # on the whole GPU, which is what its unit utilisations are meant to say. (Look-ups and traffic per ray do not depend on it.)
+  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc/pass_$i -- ${CMD/probe=0/probe=0,lanes=1} --cpu-seconds 0 --no-in-flight-check > $out/pmc_$i.log 2>&1 || { echo "pmc pass $i ($set) failed"; tail -5 $out/pmc_$i.log; }
   [ $i = 1 ] && grep '^{' $out/pmc_$i.log | tail -1 > $out/pmc/bench_pass.json
 done
 python3 tools/pmc_roofline.py $out/pmc $kern $out/counters_$kern.json "$CMD (PMC passes: --cpu-seconds 0)" > $out/pmc_roofline.log 2>&1 || tail -5 $out/pmc_roofline.log
