@@ -34,9 +34,6 @@
 #ifndef RT_TE_REG
 #define RT_TE_REG 1        // trace_wave: a light query's tE rides in a register instead of being re-read from the hit record when a leaf step finds a hit
 #endif
-#ifndef RT_HOT_AS
-#define RT_HOT_AS 0        // trace_wave: LDS and global loads of a child pair kept apart by address space (no FLAT instructions)
-#endif
 #ifndef RT_TRI_X4
 #define RT_TRI_X4 1        // trace_wave, leaf step: a triangle's positions as three aligned dwordx4 loads
 #endif
@@ -970,28 +967,12 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
             if ((int32_t)cur >= 0) {
                 float4 q0, q1, q2;
                 float2 lk;
-#if RT_HOT_AS
-                // The two sources are named by their address spaces. Left to itself the compiler merges the two branches into one
-                // set of loads through a generic pointer, i.e. FLAT instructions: those go through the vector memory pipeline even
-                // when the address is in LDS (the very pipeline the table is there to relieve), count in vmcnt and lgkmcnt alike
-                // and complete out of order, so every wait behind them is a wait for everything.
+                // (Left as written, the compiler merges the two branches into one set of loads through a generic pointer, FLAT
+                // instructions that reach LDS through the vector memory pipeline. Naming the address spaces — ds_read_b128 on one side,
+                // global_load on the other — measured 1.2 % SLOWER: both branches write the same registers, so the LDS reads are made
+                // to wait for the other lanes' global loads before they are issued. profiles/README.md, "r03 small results".)
                 if (HOT && cur < min(sc.hotNodes, 2u * (uint32_t)HOT)) {
-                    // a child pair of a mesh's top levels: from the work-group's LDS copy (ds_read_b128 x 3 + ds_read_b64)
-                    const RT_AS_LDS rt_f4v* ph = (const RT_AS_LDS rt_f4v*)hotLds + 2 * cur;
-                    const rt_f4v a = ph[0], b = ph[1], c = ph[2];
-                    const rt_f2v l = *(const RT_AS_LDS rt_f2v*)(ph + 3);
-                    q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w);
-                    lk = make_float2(l.x, l.y);
-                } else {
-                    const RT_AS_GLOBAL rt_f4v* pr = (const RT_AS_GLOBAL rt_f4v*)sc.nodesPk + 2 * (size_t)cur;
-                    const rt_f4v a = pr[0], b = pr[1], c = pr[2];
-                    const rt_f2v l = *(const RT_AS_GLOBAL rt_f2v*)(pr + 3);
-                    q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w);
-                    lk = make_float2(l.x, l.y);
-                }
-#else
-                if (HOT && cur < min(sc.hotNodes, 2u * (uint32_t)HOT)) {
-                    // a child pair of a mesh's top levels: from the work-group's LDS copy, not through the vector memory pipeline
+                    // a child pair of a mesh's top levels: from the work-group's LDS copy
                     const float4* ph = hotLds + 2 * cur;
                     q0 = ph[0]; q1 = ph[1]; q2 = ph[2];
                     lk = *(const float2*)(ph + 3);
@@ -1000,7 +981,6 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     q0 = pr[0]; q1 = pr[1]; q2 = pr[2];
                     lk = *(const float2*)(pr + 3);
                 }
-#endif
                 if (STATS) RT_STAMP_AFTER_LOADS(wt.dbgLoad[2], tStep);
                 float d1, d2;
                 box_intersect_pair(q0, q1, q2, troXY, invXY, zOI, d1, d2);
