@@ -421,6 +421,8 @@ int  rt_gather_strips(rt_ctx* ctx, const float* d_strip, uint32_t width, uint32_
  * of ranks 0 .. nRanks - 1 one after the other (rank r: its ceil((height - r) / nRanks) rows in order), d_frame receives the
  * frame's rows. Asynchronous on the ctx stream. (tests: the row arithmetic for heights that nRanks does not divide) */
 int  rt_deinterleave_strips(rt_ctx* ctx, const float* d_strips, uint32_t width, uint32_t height, int nRanks, float* d_frame);
+/* ... the same with host buffers (copied in and out; blocking) */
+int  rt_deinterleave_strips_host(rt_ctx* ctx, const float* strips, uint32_t width, uint32_t height, int nRanks, float* frame);
 
 /* device self-test of the deterministic-math build (must equal RT_SELFTEST_EXPECT) */
 int  rt_device_selftest(rt_ctx* ctx, uint32_t* bitsOut);

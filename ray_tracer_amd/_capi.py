@@ -159,6 +159,7 @@ SYMBOLS = {
     "rt_comm_destroy": (C.c_int, [_vp]),
     "rt_gather_strips": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_int, _vp]),
     "rt_deinterleave_strips": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_int, _vp]),
+    "rt_deinterleave_strips_host": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_int, _vp]),
     "rt_device_selftest": (C.c_int, [_vp, _P(C.c_uint32)]),
     "rt_host_selftest": (C.c_uint32, []),
     "rt_device_math_probe": (C.c_int, [_vp, C.c_uint32, _P(C.c_float), _P(C.c_float)]),

@@ -69,6 +69,7 @@ struct rt_ctx {
     // run under the other part's traversal. Part 0 is the ctx stream itself; the others fork from it and join it.
     hipStream_t sideStream[RT_MAX_LANES - 1] = {};
     hipEvent_t forkEvent = nullptr, joinEvent[RT_MAX_LANES - 1] = {}, pollEventSide[RT_MAX_LANES - 1] = {};
+    bool lanesSet = false;                // "lanes" given explicitly: no automatic fall-back to one part
     int lanes = 3;                        // rt_set_tuning("lanes", 1..RT_MAX_LANES)
     uint32_t lanesMinSlots = 1u << 20;    // dispatches of fewer paths than this stay in one part
     hipStream_t curStream = nullptr;      // the stream and counters of the part whose launches are being built (launch_trace)
@@ -1195,6 +1196,11 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
     // Part 0 runs on the ctx stream, the others fork from it after the ray generation and join it before the image is written.
     int nLanes = (fp.samples > 0 && nSlots >= c->lanesMinSlots) ? std::max(1, std::min(c->lanes, (int)RT_MAX_LANES)) : 1;
     if (c->phaseStats) nLanes = 1;  // the diagnostic kernel's statistics are per launch
+    // One scene shape loses by it (tools/lanes_table.py): long rays that walk into many placed objects (C5: sixteen instanced dragons,
+    // ~190 executed box tests per ray; 116.1 ms per frame in one part against 121.2 in three at 1080p, 472 against 492 at 4K).
+    // Every placed object a ray enters costs a set-up round that reloads the ray from its path state in HBM, so that traversal
+    // competes with the other parts' k_shade for HBM instead of complementing it. Such scenes keep one part unless "lanes" was set.
+    if (!c->lanesSet && c->cull && c->boxPerRay >= 150.0) nLanes = 1;
     for (int l = 1; l < nLanes; l++) {
         if (!c->sideStream[l - 1]) {
             if (hipStreamCreateWithFlags(&c->sideStream[l - 1], hipStreamNonBlocking) != hipSuccess) { c->sideStream[l - 1] = nullptr; nLanes = l; break; }
@@ -1517,7 +1523,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "batch_fixed") { if (value < 0 || value > 4096) return c->fail("batch_fixed out of range"); c->batchFixed = value; }
     else if (k == "phase_stats") { if (value < 0) return c->fail("phase_stats >= 0"); c->phaseStats = value; }
     else if (k == "object_tree_min") { if (value < 0) return c->fail("object_tree_min >= 0"); c->objTreeMin = value; }
-    else if (k == "lanes") { if (value < 1 || value > RT_MAX_LANES) return c->fail("lanes: 1..4 (parts of a multi-kernel dispatch, each on its own stream)"); c->lanes = value; }
+    else if (k == "lanes") { if (value < 1 || value > RT_MAX_LANES) return c->fail("lanes: 1..4 (parts of a multi-kernel dispatch, each on its own stream)"); c->lanes = value; c->lanesSet = true; }
     else if (k == "lane_grid_pct") { if (value < 10 || value > 100) return c->fail("lane_grid_pct: 10..100"); c->laneGridPct = value; }
     else if (k == "lanes_min_kslots") { if (value < 0) return c->fail("lanes_min_kslots >= 0"); c->lanesMinSlots = (uint32_t)value << 10; }
     else if (k == "blocks_per_cu") { if (value < 0 || value > 8) return c->fail("blocks_per_cu: 0..8"); c->blocksPerCU = value; }
@@ -1813,6 +1819,21 @@ int rt_deinterleave_strips(rt_ctx* c, const float* d_strips, uint32_t width, uin
     hipLaunchKernelGGL(k_deinterleave_rows, dim3((unsigned)((n4 + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, c->stream,
                        (const float4*)d_strips, (float4*)d_frame, width, height, (uint32_t)nRanks);
     RT_HIP(c, hipGetLastError());
+    return 0;
+}
+
+int rt_deinterleave_strips_host(rt_ctx* c, const float* strips, uint32_t width, uint32_t height, int nRanks, float* frame) {
+    if (!c || !strips || !frame) return -1;
+    RT_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)width * height * 16;
+    int rc = dev_alloc(c, c->scratchBuf, 2 * bytes);
+    if (rc) return rc;
+    float* ds = (float*)c->scratchBuf.p;
+    float* df = (float*)((char*)c->scratchBuf.p + bytes);
+    RT_HIP(c, hipMemcpyAsync(ds, strips, bytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = rt_deinterleave_strips(c, ds, width, height, nRanks, df))) return rc;
+    RT_HIP(c, hipMemcpyAsync(frame, df, bytes, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -28,14 +28,8 @@
 #include "rt_probe.h"
 
 #define RT_WAVE 64
-#ifndef RT_PRELOAD_TOP
-#define RT_PRELOAD_TOP 0   // trace_wave: the stack top a round's tail may pop is read at the start of the round
-#endif
 #ifndef RT_TE_REG
-#define RT_TE_REG 1        // trace_wave: a light query's tE rides in a register instead of being re-read from the hit record when a leaf step finds a hit
-#endif
-#ifndef RT_TRI_X4
-#define RT_TRI_X4 1        // trace_wave, leaf step: a triangle's positions as three aligned dwordx4 loads
+#define RT_TE_REG 1        // trace_wave<ROOMY>: a light query's tE rides in a register instead of being re-read from the hit record when a leaf step finds a hit
 #endif
 #ifndef RT_OBJTREE
 #define RT_OBJTREE 1       // trace_wave, set-up step: the object hierarchy's block jumps compiled in (CULL kernels)
@@ -663,7 +657,10 @@ struct WaveTotals {
 // goes straight to the interior step; pushes and pops are unconditional LDS accesses with
 // predicated pointer updates; the full vote, the refill and the leaf / setup steps live on a slow
 // path that is only entered when fewer than `fastLanes` lanes are at interior nodes.
-template <int STACK, bool OVF, bool PIX, bool STATS, bool LOCAL, bool CULL, int HOT = 0>
+// ROOMY: the kernel is built for five work-groups per CU (96 registers per lane): a light query's tE rides in a register there
+// (-2 % on the bench frame). With the 80 registers of six work-groups per CU, and in the fused kernel, one more live register
+// means one more spill: measured there, it loses (Cornell + bunny +3 %, C5 at 4K +1 %).
+template <int STACK, bool OVF, bool PIX, bool STATS, bool LOCAL, bool CULL, int HOT = 0, bool ROOMY = false>
 __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& ps, const TracePwArgs& ta, uint32_t* stack, uint32_t* ovf,
                                            size_t ovfStride, const uint32_t* localList, uint32_t n, WaveTotals& wt, const uint2* metaLds,
                                            const float4* hotLds = nullptr) {
@@ -725,13 +722,6 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
     for (;;) {
         const unsigned long long tRound = STATS ? clock64() : 0ull;
         int roundKind = 2;
-#if RT_PRELOAD_TOP
-        // The stack entry the tail may pop, read before the round's step instead of after it: a lane that pushes in the interior
-        // step goes on into the near child (dFar < best implies dNear < best) and never pops in the same round, and no other step
-        // pushes at all, so whenever the tail pops, the top of the stack is what it was here. One LDS round trip less on the
-        // dependent chain of every round (the read now returns while the round's node fetch is in flight).
-        const uint32_t topPre = stack[(OVF ? min((sp ? sp : 1u) - 1u, (uint32_t)STACK) : (sp ? sp : 1u) - 1u) * RT_WAVE];
-#endif
         const unsigned long long mI = __ballot((int32_t)cur >= 0);
         uint32_t nI = __popcll(mI);
         bool runI = nI >= thr;
@@ -805,7 +795,6 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     if (cnt != 0u) {
                         // one or two triangles: both fetched before either is tested
                         const uint32_t j1 = jEnd - 1u;
-#if RT_TRI_X4
                         // Whole 16-byte vectors from the global address space: three aligned loads per triangle. (Through float4, whose
                         // padding words are never read, the compiler fetched a triangle's 44 bytes as 8 + 16 at offset 4 + 8 + 12: four
                         // instructions, one of them straddling two 16-byte slots.)
@@ -813,18 +802,11 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         const RT_AS_GLOBAL rt_f4v* tp1 = (const RT_AS_GLOBAL rt_f4v*)sc.triPos + 3 * (size_t)j1;
                         const rt_f4v a0 = tp0[0], b0 = tp0[1], c0 = tp0[2];
                         const rt_f4v a1 = tp1[0], b1 = tp1[1], c1 = tp1[2];
-#else
-                        const float4 a0 = sc.triPos[3 * (size_t)j], b0 = sc.triPos[3 * (size_t)j + 1], c0 = sc.triPos[3 * (size_t)j + 2];
-                        const float4 a1 = sc.triPos[3 * (size_t)j1], b1 = sc.triPos[3 * (size_t)j1 + 1], c1 = sc.triPos[3 * (size_t)j1 + 2];
-#endif
                         if (STATS) RT_STAMP_AFTER_LOADS(wt.dbgLoad[3], tLeaf);
                         const rt_vec3 o = rt_v3(troXY.x, troXY.y, zOI.x);
                         const TriHit h0 = tri_intersect(o, trd, rt_v3(a0.x, a0.y, a0.z), rt_v3(b0.x, b0.y, b0.z), rt_v3(c0.x, c0.y, c0.z), __float_as_uint(a0.w) != 0u);
                         if (h0.didHit && h0.dst < best) { best = h0.dst; bestObj = cur_object(); bestTri = j; closer = true; }
-                        // (a one-triangle step tests its triangle twice, which changes nothing — the second result can never win the strict
-                        // `<` against the first — and keeps both triangles' loads in one block ahead of both tests: with the second test
-                        // behind a branch the compiler moved the second triangle's loads behind the first test, two round trips per step)
-                        if (!RT_TRI_X4 ? j1 != j : true) {
+                        if (j1 != j) {
                             const TriHit h1 = tri_intersect(o, trd, rt_v3(a1.x, a1.y, a1.z), rt_v3(b1.x, b1.y, b1.z), rt_v3(c1.x, c1.y, c1.z), __float_as_uint(a1.w) != 0u);
                             if (h1.didHit && h1.dst < best) { best = h1.dst; bestObj = cur_object(); bestTri = j1; closer = true; }
                         }
@@ -840,7 +822,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     // is "not emissive" whatever else the ray meets, so it ends here and reports no hit, which is what shade_path
                     // reads as "not emissive". tE is re-read from the ray's hit record on the rare step that finds a hit rather
                     // than held in a register through the loop. The leaf counts in full, as the shader counts it (:310).
-                    if (closer && best < (RT_TE_REG ? earlyT : ps.hit(id & 3u)[id >> 2].w)) {
+                    if (closer && best < ((RT_TE_REG && ROOMY) ? earlyT : ps.hit(id & 3u)[id >> 2].w)) {
                         if ((int32_t)cur < 0 && cur < RT_CUR_LEAF_MAX) {  // triangles of this leaf not yet stepped through
                             const uint32_t rest = (cur >> RT_LEAF_CNT_SHIFT) & 7u;
                             if (PIX) rayTri += rest; else wt.totTri += rest;
@@ -881,7 +863,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         best = seed.x; bestObj = __float_as_uint(seed.y); bestTri = 0;
                         plain = ray_is_plain(wo, wd);
                         reach = __float_as_uint(seed.z);
-                        earlyT = seed.w;
+                        if (RT_TE_REG && ROOMY) earlyT = seed.w;
                         obj = 0; sp = 0;
                         if (PIX) { rayBox = 0; rayTri = 0; }
                         wt.totRays++;
@@ -1005,17 +987,12 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
             const bool need = cur == RT_CUR_NEED;
             const bool has = sp > 0;
             uint32_t top;
-#if RT_PRELOAD_TOP
-            top = topPre;
-            if (OVF && need && sp > (uint32_t)STACK) top = ((const RT_AS_GLOBAL uint32_t*)ovf)[(sp - 1u - STACK) * ovfStride];
-#else
             if (OVF) {
                 top = stack[min((has ? sp : 1u) - 1u, (uint32_t)STACK) * RT_WAVE];
                 if (need && sp > (uint32_t)STACK) top = ((const RT_AS_GLOBAL uint32_t*)ovf)[(sp - 1u - STACK) * ovfStride];  // (named global: no FLAT load)
             } else {
                 top = stack[((has ? sp : 1u) - 1u) * RT_WAVE];
             }
-#endif
             const bool objLeft = obj < sc.objectCount;
             const bool ident = (nxFlags & 1u) && plain;  // identity transform: register moves only
             const uint32_t whenEmpty = objLeft ? (ident ? (atWorld ? nxW : RT_CUR_WORLD) : RT_CUR_SETUP) : RT_CUR_DONE;
@@ -1068,7 +1045,7 @@ __global__ __launch_bounds__(RT_BLOCK, BLOCKS) void k_trace_pw(DevScene sc, Path
     const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
     WaveTotals wt;
     const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
-    trace_wave<STACK, OVF, PIX, STATS, false, CULL, HOT>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt, s_meta, s_hot);
+    trace_wave<STACK, OVF, PIX, STATS, false, CULL, HOT, BLOCKS == 5>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt, s_meta, s_hot);
 
     const uint32_t skipTrips = STATS ? wave_sum_u32(wt.dbgWait[3]) : 0u;
     if (STATS && lane_id() == 0) {

@@ -423,6 +423,14 @@ class Renderer:
         self._check(self._l.rt_deinterleave_strips(self._h, C.c_void_p(strips_ptr), width, height, int(n_ranks), C.c_void_p(frame_ptr)),
                     "rt_deinterleave_strips")
 
+    def deinterleave_strips_host(self, strips, n_ranks):
+        """[H, W, 4] float32 strips of ranks 0..n_ranks-1 one after the other -> the [H, W, 4] frame (through the device kernel)."""
+        strips = np.ascontiguousarray(strips, np.float32)
+        out = np.empty_like(strips)
+        self._check(self._l.rt_deinterleave_strips_host(self._h, strips.ctypes.data_as(C.c_void_p), strips.shape[1], strips.shape[0], int(n_ranks),
+                                                        out.ctypes.data_as(C.c_void_p)), "rt_deinterleave_strips_host")
+        return out
+
     def math_probe(self, inputs):
         """include/rt_probe.h evaluated on the device: [n, 32] float32 -> [n, 64] float32."""
         x = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, 32)

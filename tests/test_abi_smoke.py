@@ -96,14 +96,10 @@ def test_strips_of_n_ranks_become_the_frame(renderer, n_ranks, height):
     and fewer rows than ranks: rank r's strip holds rows r, r + N, ... and the strips lie rank after rank (the RCCL
     gather itself has only ever run with one rank, where this step is the identity)."""
     import numpy as np
-    import torch
     width = 37
     frame = np.arange(height * width * 4, dtype=np.float32).reshape(height, width, 4)
     strips = np.concatenate([frame[r::n_ranks] for r in range(n_ranks)], axis=0)
     assert strips.shape == frame.shape
-    d_strips = torch.from_numpy(strips).cuda()
-    d_frame = torch.full((height, width, 4), -1.0, dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
-    renderer.deinterleave_strips(d_strips.data_ptr(), width, height, n_ranks, d_frame.data_ptr())
-    renderer.sync()
-    assert np.array_equal(d_frame.cpu().numpy(), frame)
+    # (host buffers through the library's own copies: a second HIP runtime in this process — torch's, or libamdhip64 loaded by
+    # hand — does not see the device the library's runtime holds)
+    assert np.array_equal(renderer.deinterleave_strips_host(strips, n_ranks), frame)
