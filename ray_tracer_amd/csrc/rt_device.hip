@@ -1166,11 +1166,13 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
         c->pixStats = false;
     }
     const bool shortRays = c->boxPerRay >= 0.0 && c->boxPerRay < (double)c->fusedBelowBoxTests;
-    // the longer the rays, the earlier the global queue of the multi-kernel pipeline pays: Sponza (153 box tests per ray)
-    // switches near 4 M paths (two 1080p frames: 113.5 ms per step either way; four: 103.9 against 111.3), Sponza + 16
-    // dragons (213) near 2 M (one 1080p frame: fused 187 ms per 8 spp against 195; a 4K frame: 369 against 299)
+    // the longer the rays, the earlier the global queue of the multi-kernel pipeline pays — and with the dispatch in overlapping
+    // parts earlier than it used to (tools/size_sweep.py, one 1080p frame = 2.07 M paths, fused / multi-kernel in parts: Sponza,
+    // 153 executed box tests per ray, 113.8 / 103.4 ms; Sponza + 16 dragons 167.2 / 162.5; the klein bottle x 8, 84 tests,
+    // 70.2 / 76.6; half a frame, 1.04 M paths: 61.5 / 66.3, 91.9 / 106.8, 41.5 / 57.4): 4 M paths up to 90 tests per ray, falling
+    // to 1.5 M at 150
     double sizeLimit = (double)c->fusedBelowPixels;
-    if (c->boxPerRay > 160.0) sizeLimit = std::max(0.5 * sizeLimit, sizeLimit - (c->boxPerRay - 160.0) * 38000.0);
+    if (c->boxPerRay > 90.0) sizeLimit = std::max(0.375 * sizeLimit, sizeLimit - (c->boxPerRay - 90.0) * (0.625 / 60.0) * sizeLimit);
     // (the paths of all the frames of the dispatch count: four frames of a quarter of a 4K frame are a 4K frame's worth)
     // Short rays keep the fused pipeline at any size — unless the traversal misses the caches: a scene whose hot data (child pairs
     // and triangle positions) exceeds one XCD's 4 MB of L2 is bound by latency even with few tests per ray, and from 16 M paths the
@@ -1200,7 +1202,8 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
     // ~190 executed box tests per ray; 116.1 ms per frame in one part against 121.2 in three at 1080p, 472 against 492 at 4K).
     // Every placed object a ray enters costs a set-up round that reloads the ray from its path state in HBM, so that traversal
     // competes with the other parts' k_shade for HBM instead of complementing it. Such scenes keep one part unless "lanes" was set.
-    if (!c->lanesSet && c->cull && c->boxPerRay >= 150.0) nLanes = 1;
+    // (from 8 M paths on: a single 1080p frame of the same scene still gains 7 % from its parts, whose launches are short against their tails)
+    if (!c->lanesSet && c->cull && c->boxPerRay >= 150.0 && nSlots >= (8u << 20)) nLanes = 1;
     for (int l = 1; l < nLanes; l++) {
         if (!c->sideStream[l - 1]) {
             if (hipStreamCreateWithFlags(&c->sideStream[l - 1], hipStreamNonBlocking) != hipSuccess) { c->sideStream[l - 1] = nullptr; nLanes = l; break; }
