@@ -33,6 +33,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # see ray_tracer_amd.tiling.prepare_rccl_env (set before torch loads RCCL)
+# A dispatch runs in three parts on three HIP streams (rt_amd.h, "lanes"); ROCm maps a process's streams onto GPU_MAX_HW_QUEUES
+# hardware queues (4 by default) and two streams on one queue run one after the other: with torch's and RCCL's own streams in the
+# process the parts could end up sharing (measured with a fourth part: 103.7 ms per step on 4 queues, 82.2 on 8). Read at HIP's start-up.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 GATHER_PEAK_LOOKUPS_PER_CLK_CU = 1.39   # tools/gather_bench.hip (profiles/README.md, "what a vector load costs")

@@ -363,7 +363,10 @@ int  rt_get_trace_busy_ms(rt_ctx* ctx, double* msOut);
  *                    from and joined to the ctx stream), so that one part's shading kernel and the draining tail of its
  *                    traversal launch run under the other parts' traversal; 1..4, default 3
  *   "lane_grid_pct"  ... each part's traversal launch taking this share of the resident work-groups (default 50: three parts
- *                    oversubscribe the GPU 1.5 times, so a part in its shading kernel leaves no traversal slot empty)
+ *                    oversubscribe the GPU 1.5 times, so a part in its shading kernel leaves no traversal slot empty).
+ *                    The parts only overlap while their streams sit on different hardware queues: ROCm deals a process's
+ *                    streams onto GPU_MAX_HW_QUEUES queues (default 4); a host with many streams of its own should start
+ *                    with that variable raised (bench.py sets 8)
  *   "trace_variant"  0 = one ray per lane (k_trace), 1 = persistent waves (k_trace_pw)
  *   "refill", "mk_refill", "chunk", "w_setup", "w_leaf", "fast_lanes", "lds_stack", "blocks_per_cu",
  *   "tile_slots", "phase_stats": traversal scheduling details, see DESIGN.md

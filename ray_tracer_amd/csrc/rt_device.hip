@@ -1175,12 +1175,13 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
     if (c->boxPerRay > 90.0) sizeLimit = std::max(0.375 * sizeLimit, sizeLimit - (c->boxPerRay - 90.0) * (0.625 / 60.0) * sizeLimit);
     // (the paths of all the frames of the dispatch count: four frames of a quarter of a 4K frame are a 4K frame's worth)
     // Short rays keep the fused pipeline at any size — unless the traversal misses the caches: a scene whose hot data (child pairs
-    // and triangle positions) exceeds one XCD's 4 MB of L2 is bound by latency even with few tests per ray, and from 16 M paths the
+    // and triangle positions) exceeds one XCD's 4 MB of L2 is bound by latency even with few tests per ray, and from 10 M paths the
     // multi-kernel pipeline's extra resident waves and overlapping parts win there too (Cornell + bunny, 33 box tests per ray, ten
-    // 1080p frames: 36.4 against 38.7 ms per frame; + dragon 39.6 against 41.0), while small scenes (bobadog, the 45-object scene)
+    // 1080p frames: 36.1 against 38.0 ms per frame; + dragon 36.3 against 40.1; level between four and six frames:
+    // tools/frames_sweep.py), while small scenes (bobadog, the 45-object scene)
     // and scenes of very short rays (fewer than 25 executed tests: 232 k loose triangles on a floor) stay fused (tools/heuristics_table.py)
     const bool bigScene = (uint64_t)c->sc.nodeCount * 32u + (uint64_t)c->sc.triCount * 48u > (4ull << 20);
-    const bool shortButMissing = shortRays && bigScene && c->boxPerRay >= 25.0 && nSlots >= (16u << 20);
+    const bool shortButMissing = shortRays && bigScene && c->boxPerRay >= 25.0 && nSlots >= (10u << 20);
     c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (((double)nSlots < sizeLimit || (shortRays && !shortButMissing)) ? 1 : 0);
     if (c->lastPipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch
         rc = launch_fused(c, fp, fb);

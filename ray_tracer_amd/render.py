@@ -36,7 +36,9 @@ import time
 
 import numpy as np
 
-from . import engine, scenes
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before the first HIP call: the renderer's three streams beside torch's and RCCL's (rt_amd.h, "lane_grid_pct")
+
+from . import engine, scenes  # noqa: E402
 
 
 def build_parser():

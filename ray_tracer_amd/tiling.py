@@ -18,6 +18,9 @@ def prepare_rccl_env():
     HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's peer buffers fail with `hipIpcGetMemHandle: invalid argument`.
     (Already exported on the GPU boxes; set here for any other launcher.)"""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the renderer's three streams next to torch's and RCCL's: more hardware queues than ROCm's default four, so that no two of them
+    # share one (streams on one queue serialise; only effective when set before the process's first HIP call, as bench.py does)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def rows_of_rank(height, rank, world):
