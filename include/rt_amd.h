@@ -361,7 +361,8 @@ int  rt_get_trace_busy_ms(rt_ctx* ctx, double* msOut);
  *   "lanes"          multi-kernel pipeline: a dispatch of at least "lanes_min_kslots" x 1024 paths is rendered in this many
  *                    independent parts (contiguous ranges of path slots, each with its own queues and its own stream, forked
  *                    from and joined to the ctx stream), so that one part's shading kernel and the draining tail of its
- *                    traversal launch run under the other parts' traversal; 1..4, default 3
+ *                    traversal launch run under the other parts' traversal; 1..4; 0 (default) = 3, except one for
+ *                    dispatches of >= 8 M paths of scenes whose long rays walk into many placed objects (they lose by it)
  *   "lane_grid_pct"  ... each part's traversal launch taking this share of the resident work-groups (default 50: three parts
  *                    oversubscribe the GPU 1.5 times, so a part in its shading kernel leaves no traversal slot empty).
  *                    The parts only overlap while their streams sit on different hardware queues: ROCm deals a process's
@@ -386,6 +387,8 @@ int  rt_set_tuning(rt_ctx* ctx, const char* key, int value);
  * false, false, 144, 5>", "k_render_fused<24, false, false, true>"): tests/test_instantiations.py forces every instantiation in
  * the library and compares it with the oracle. The string lives in the context. */
 const char* rt_last_kernel(const rt_ctx* ctx);
+/* parts (streams) the last dispatch of the multi-kernel pipeline ran in ("lanes") */
+int  rt_last_parts(const rt_ctx* ctx);
 /* pipeline the last rt_render used (0 or 1) */
 int  rt_last_pipeline(const rt_ctx* ctx);
 /* box tests per executed ray of the uploaded scene as this context measured them (the figure the launch parameters

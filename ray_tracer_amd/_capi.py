@@ -148,6 +148,7 @@ SYMBOLS = {
     "rt_get_trace_time_ms": (C.c_int, [_vp, _P(C.c_double), _P(C.c_uint64)]),
     "rt_get_trace_busy_ms": (C.c_int, [_vp, _P(C.c_double)]),
     "rt_last_kernel": (C.c_char_p, [_vp]),
+    "rt_last_parts": (C.c_int, [_vp]),
     "rt_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "rt_last_pipeline": (C.c_int, [_vp]),
     "rt_ray_cost": (C.c_double, [_vp]),

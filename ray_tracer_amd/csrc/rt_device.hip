@@ -75,6 +75,7 @@ struct rt_ctx {
     hipStream_t curStream = nullptr;      // the stream and counters of the part whose launches are being built (launch_trace)
     uint32_t* curCounts = nullptr;
     int curLane = 0;
+    int lastParts = 1;                    // parts the last multi-kernel dispatch ran in (rt_last_parts)
     int curGridPct = 100;                 // share of the resident work-groups a k_trace_pw launch of the current part takes
     int laneGridPct = 50;                 // rt_set_tuning("lane_grid_pct"): that share while a dispatch runs in several parts
     uint32_t capacity = 0;  // pixels the state buffers hold
@@ -1213,6 +1214,7 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
         }
     }
     if (nLanes > 1 && !c->forkEvent && hipEventCreateWithFlags(&c->forkEvent, hipEventDisableTiming) != hipSuccess) { c->forkEvent = nullptr; nLanes = 1; }
+    c->lastParts = nLanes;
     struct Lane {
         hipStream_t stream; uint32_t* counts; hipEvent_t poll; uint32_t begin, n, ubActive; int cur; bool pollPending, done;
     } lane[RT_MAX_LANES];
@@ -1495,6 +1497,7 @@ int rt_get_trace_time_ms(rt_ctx* c, double* ms, uint64_t* launches) {
 }
 
 const char* rt_last_kernel(const rt_ctx* c) { return c ? c->lastKernel : ""; }
+int rt_last_parts(const rt_ctx* c) { return c ? c->lastParts : 0; }
 
 int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     if (!c || !key) return -1;
@@ -1527,7 +1530,7 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "batch_fixed") { if (value < 0 || value > 4096) return c->fail("batch_fixed out of range"); c->batchFixed = value; }
     else if (k == "phase_stats") { if (value < 0) return c->fail("phase_stats >= 0"); c->phaseStats = value; }
     else if (k == "object_tree_min") { if (value < 0) return c->fail("object_tree_min >= 0"); c->objTreeMin = value; }
-    else if (k == "lanes") { if (value < 1 || value > RT_MAX_LANES) return c->fail("lanes: 1..4 (parts of a multi-kernel dispatch, each on its own stream)"); c->lanes = value; c->lanesSet = true; }
+    else if (k == "lanes") { if (value < 0 || value > RT_MAX_LANES) return c->fail("lanes: 1..4 (parts of a multi-kernel dispatch, each on its own stream), 0 = automatic"); c->lanes = value ? value : 3; c->lanesSet = value != 0; }
     else if (k == "lane_grid_pct") { if (value < 10 || value > 100) return c->fail("lane_grid_pct: 10..100"); c->laneGridPct = value; }
     else if (k == "lanes_min_kslots") { if (value < 0) return c->fail("lanes_min_kslots >= 0"); c->lanesMinSlots = (uint32_t)value << 10; }
     else if (k == "blocks_per_cu") { if (value < 0 || value > 8) return c->fail("blocks_per_cu: 0..8"); c->blocksPerCU = value; }

@@ -382,6 +382,10 @@ class Renderer:
         """Traversal kernel instantiation of the last launch, e.g. 'k_trace_pw<20, false, false, false, false, 144, 5>'."""
         return self._l.rt_last_kernel(self._h).decode()
 
+    def last_parts(self):
+        """Parts (streams) the last multi-kernel dispatch ran in."""
+        return self._l.rt_last_parts(self._h)
+
     def last_pipeline(self):
         """0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline."""
         return self._l.rt_last_pipeline(self._h)
