@@ -230,11 +230,12 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     const bool pix = c->pixStats || ta.perRayBox;
     // top-level pairs from LDS (k_trace_pw<HOT>): what 160 KB of LDS per CU leave beside the stacks. hot_pairs 1: six work-groups
     // per CU, 2: five (more pairs, no spills at 96 registers)
-    constexpr int HOT6 = OVF ? 0 : STACK == 8 ? 192 : STACK == 16 ? 136 : STACK == 20 ? 72 : 0;
+    // (the overflow-stack kernel with 16 entries in LDS keeps six work-groups AND 120 pairs: deep BVHs, see launch_trace)
+    constexpr int HOT6 = OVF ? (STACK == 16 ? 120 : 0) : STACK == 8 ? 192 : STACK == 16 ? 136 : STACK == 20 ? 72 : 0;
     constexpr int HOT5 = OVF ? 0 : STACK == 24 ? 80 : STACK == 20 ? 144 : 192;
     int hotMode = (!pix && !c->phaseStats && c->sc.hotNodes > 0) ? c->hotPairs : 0;
     if (hotMode == 1 && HOT6 == 0) hotMode = 2;   // (a 24-entry stack leaves no room at six work-groups)
-    if (hotMode == 2 && HOT5 == 0) hotMode = 0;   // (overflow-stack instantiations: not built with the table)
+    if (hotMode == 2 && HOT5 == 0) hotMode = HOT6 ? 1 : 0;   // (overflow-stack instantiations: the table only beside 16-entry stacks)
     int perCU = c->blocksPerCU;
     if (perCU <= 0) {
         hipError_t e;
@@ -426,7 +427,11 @@ int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
         else if (d <= 48) launch_v0_t<48>(c, maxRays, ta);
         else launch_v0_t<64>(c, maxRays, ta);
     } else {  // persistent waves; at most 24 entries in LDS, deeper ones in the overflow buffer
-        const uint32_t cap = (uint32_t)c->ldsStackCap;
+        // BVHs deeper than 24: 16 entries in LDS, the rest in the overflow buffer (the stack only holds far siblings and is rarely
+        // that deep), which leaves room for 120 top-level pairs beside six work-groups per CU: C5 at 4K 474 -> 468 ms per step,
+        // flattened 471 -> 462, 1080p 117.5 -> 115.6 (Cornell + dragon: level)
+        const bool tableWanted = c->hotPairs && c->sc.hotNodes > 0 && !c->phaseStats && !(c->pixStats || ta.perRayBox);  // (launch_pw_t's condition)
+        const uint32_t cap = (d > 24u && c->ldsStackCap >= 24 && tableWanted) ? 16u : (uint32_t)c->ldsStackCap;
         if (c->cull) {
             if (d <= 8) rc = launch_pw_t<8, false, true>(c, maxRays, ta);
             else if (cap < 16) rc = launch_pw_t<8, true, true>(c, maxRays, ta);
