@@ -48,8 +48,8 @@ SCENE_NAMES = {"cornell": "Cornell", "bunny": "Cornell + bunny", "dragon": "Corn
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default="sponza", choices=["cornell", "bunny", "dragon", "sponza", "sponza_dragons", "sponza_dragons_flat"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
