@@ -25,5 +25,10 @@ def renderer(built):
     """One device context for all GPU tests (single process, single GPU)."""
     from ray_tracer_amd import engine
     r = engine.Renderer(0)
+    # soak runs: RT_TEST_TUNE="lanes_min_kslots=1,object_tree_min=2" puts every test's small scenes through code that only big
+    # ones reach by default (the dispatch in parts, the object hierarchy); RT_RANDOM_SEEDS=N widens the seeded random-scene tests
+    for kv in filter(None, os.environ.get("RT_TEST_TUNE", "").split(",")):
+        k, v = kv.split("=")
+        r.set_tuning(k, int(v))
     yield r
     r.close()
