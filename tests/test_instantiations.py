@@ -3,9 +3,10 @@
 The traversal is one device function (trace_wave) compiled into ~80 kernels: k_trace_pw<STACK, OVF, PIX, STATS, CULL, HOT, BLOCKS>,
 k_render_fused<STACK, OVF, PIX, CULL> and the one-ray-per-lane k_trace<STACK>. Which one runs follows from the scene (deepest
 leaf, placed objects), the dispatch (heat maps) and knobs — so the other parity tests cover whatever their scenes happen to
-select. Round 2 met a compiler pass (si-optimize-exec-masking-pre-ra, ROCm 7.2.0) that miscompiled ONE instantiation twice while
-all others stayed right, and the library has been built with that pass off since (__graft_entry__.HIPFLAGS). This test is the
-guard for that decision: it reads the list of instantiations out of the built library (host stubs in its symbol table), forces
+select. Rounds 2 and 3 met two passes of ROCm 7.2.0's AMDGPU backend (si-optimize-exec-masking-pre-ra, si-opt-vgpr-liverange)
+that each miscompiled ONE heavily spilling instantiation of k_render_fused while all others stayed right, and the library is
+built with both off (__graft_entry__.HIPFLAGS; tools/miscompile_repro.sh). This test is the guard for that decision — on the
+library built with si-opt-vgpr-liverange left on it fails —: it reads the list of instantiations out of the built library (host stubs in its symbol table), forces
 each of them through scenes of the right BVH depth, with and without placed objects, heat maps, phase statistics, the three
 top-level-table modes and the LDS stack caps, asks the library which kernel it launched (rt_last_kernel), compares pixels and
 counters with the oracle bit for bit, and fails if any instantiation in the binary was not reached."""
