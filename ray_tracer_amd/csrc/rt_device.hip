@@ -113,6 +113,7 @@ struct rt_ctx {
     double segPerPath = -1.0;             // path segments per pixel sample of this scene, from the same snapshots (< 0: not measured yet)
     unsigned long long snapSeg = 0, snapPaths = 0;
     int refill = 8;         // k_trace_pw: idle lanes that trigger a refill
+    bool refillMkSet = false, wSetupSet = false;  // given explicitly (else by the scene's ray length, launch_pw_t)
     int refillMk = 16;      // the same for k_trace_pw over the global queue (ten frames of the bench frame in flight: 8 -> 99.1, 16 -> 96.6, 24 -> 97.9, 32 -> 99.3 ms per step)
     int chunk = 256;        // k_trace_pw: most queue entries reserved per atomic
     int ldsStackCap = 24;   // k_trace_pw: LDS stack entries per lane (8, 16 or 24); deeper BVHs use the overflow buffer
@@ -267,7 +268,13 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
         if (rc) return rc;
         waveTimes = (unsigned long long*)c->waveTimeBuf.p;
     }
-    TracePwArgs pa{ta.queue, ta.count, laneCounts + 4, (uint32_t)c->refillMk, (uint32_t)c->chunk, (uint32_t)c->wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, (uint32_t)c->fastShare,
+    // Long rays (the measure the pipeline choice uses) want new rays sooner and their set-up served later: idle lanes re-armed at 12
+    // instead of 16, set-up steps voted in at weight 32 instead of 16 (Sponza 81.0 -> 79.4 ms per step, C5 115.4 -> 114.1;
+    // Cornell + bunny / + dragon, short rays: +2.5 / +3.5 % with the same, so they keep 16 / 16). Knobs set by hand win.
+    const bool longRays = c->boxPerRay >= (double)c->fusedBelowBoxTests;
+    const uint32_t refillMk = c->refillMkSet ? (uint32_t)c->refillMk : (longRays ? 12u : 16u);
+    const uint32_t wSetup = c->wSetupSet ? (uint32_t)c->wSetup : (longRays ? 32u : 16u);
+    TracePwArgs pa{ta.queue, ta.count, laneCounts + 4, refillMk, (uint32_t)c->chunk, wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, (uint32_t)c->fastShare,
                    ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), waveTimes, overflow};
     {
         const bool stats = hotMode == 0 && c->phaseStats, px = hotMode == 0 && (c->phaseStats || pix);
@@ -1516,15 +1523,15 @@ int rt_set_tuning(rt_ctx* c, const char* key, int value) {
     else if (k == "fused_below_box_tests") { if (value < 0) return c->fail("fused_below_box_tests >= 0"); c->fusedBelowBoxTests = (uint32_t)value; }
     else if (k == "fused_below_pixels") { if (value < 0) return c->fail("fused_below_pixels >= 0"); c->fusedBelowPixels = (uint32_t)value; }
     else if (k == "trace_variant") { if (value < 0 || value > 1) return c->fail("trace_variant: 0 or 1"); c->traceVariant = value; }
-    else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; c->refillMk = value; }
+    else if (k == "refill") { if (value < 1 || value > 64) return c->fail("refill: 1..64"); c->refill = value; c->refillMk = value; c->refillMkSet = true; }
     else if (k == "hot_pairs") { if (value < 0 || value > 2) return c->fail("hot_pairs: 0, 1 (six work-groups per CU) or 2 (five)"); c->hotPairs = value; }
-    else if (k == "mk_refill") { if (value < 1 || value > 64) return c->fail("mk_refill: 1..64"); c->refillMk = value; }
+    else if (k == "mk_refill") { if (value < 1 || value > 64) return c->fail("mk_refill: 1..64"); c->refillMk = value; c->refillMkSet = true; }
     else if (k == "lds_stack") { if (value != 8 && value != 16 && value != 24) return c->fail("lds_stack: 8, 16 or 24"); c->ldsStackCap = value; }
     else if (k == "fast_lanes") { if (value < 0 || value > 65) return c->fail("fast_lanes: 1..65 (0: back to the defaults)"); c->fastLanesSet = value != 0; c->fastLanes = value ? value : 32; }
     else if (k == "chunk") { if (value < 1 || value > 4096) return c->fail("chunk: 1..4096"); c->chunk = value; }
-    else if (k == "w_setup") { if (value < 1 || value > 512) return c->fail("w_setup: 1..512"); c->wSetup = value; c->wSetupFused = value; }
+    else if (k == "w_setup") { if (value < 1 || value > 512) return c->fail("w_setup: 1..512"); c->wSetup = value; c->wSetupFused = value; c->wSetupSet = true; }
     else if (k == "w_leaf") { if (value < 1 || value > 512) return c->fail("w_leaf: 1..512"); c->wLeaf = value; c->wLeafFused = value; c->wLeafSet = true; }
-    else if (k == "mk_w_setup") { if (value < 1 || value > 512) return c->fail("mk_w_setup: 1..512"); c->wSetup = value; }
+    else if (k == "mk_w_setup") { if (value < 1 || value > 512) return c->fail("mk_w_setup: 1..512"); c->wSetup = value; c->wSetupSet = true; }
     else if (k == "mk_w_leaf") { if (value < 1 || value > 512) return c->fail("mk_w_leaf: 1..512"); c->wLeaf = value; }
     else if (k == "tile_slots") { c->tileSlots = value != 0; }
     else if (k == "mask_identity") { c->maskIdentity = value != 0; }
