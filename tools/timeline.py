@@ -19,3 +19,7 @@ span = ev[-1][0] - ev[0][0]
 print(f"span {span / 1e6:.2f} ms; kernels running: " + ", ".join(f"{k}: {v / span * 100:.1f} %" for k, v in sorted(hist.items())))
 tr = df[df.name.str.startswith("k_trace_pw")]
 print(f"k_trace_pw: {len(tr)} launches, mean {tr.dur.mean() / 1e6:.3f} ms, median {tr.dur.median() / 1e6:.3f} ms")
+for col in ("Queue_Id", "Stream_Id"):
+    if col in df.columns:
+        g = df[df.name.str.startswith(("k_trace_pw", "k_shade"))].groupby(col)
+        print(f"by {col}: " + "; ".join(f"{k}: {len(v)} kernels, busy {v.dur.sum() / 1e6:.1f} ms, last end at {(v.End_Timestamp.max() - ev[0][0]) / span * 100:.1f} % of the span" for k, v in g))
