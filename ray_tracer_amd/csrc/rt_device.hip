@@ -100,9 +100,10 @@ struct rt_ctx {
     int pipeline = -1;      // 0 = multi-kernel wavefront pipeline, 1 = wave-private fused pipeline (k_render_fused), -1 = by tile size
     int lastPipeline = 0;   // what the last rt_render used
     char lastKernel[96] = "";  // the traversal kernel instantiation of the last launch, as a demangler prints it (rt_last_kernel)
-    uint32_t fusedBelowPixels = 4000000;  // auto: dispatches of fewer paths than this use the fused pipeline. Sponza, 8 spp, ms per step with 1 / 2 / 4 / 8
-                                          // frames of 1080p in one dispatch: fused 117 / 113.5 / 111.3 / 110.2, multi-kernel 131.4 / 113.5 / 103.9 / 99.9
-    uint32_t fusedBelowBoxTests = 70;     // auto: ... and so do scenes whose rays are short (box tests per ray, measured)
+    uint32_t fusedBelowPixels = 4000000;  // auto: dispatches of fewer paths than this use the fused pipeline — scaled down to 1.5 M as the rays get longer
+                                          // (render_impl: sizeLimit). Sponza, 8 spp, ms per step with 1 / 2 / 4 / 10 frames of 1080p in one dispatch
+                                          // (round 3, multi-kernel in three parts): fused 113.8 / 109.4 / 107.4 / 105, multi-kernel 103.4 / 90.7 / 84.7 / 79.5
+    uint32_t fusedBelowBoxTests = 70;     // auto: ... and so do scenes whose rays are short (EXECUTED box tests per ray, measured), with one exception (render_impl)
     // box tests per ray of this scene, from counter snapshots copied back asynchronously after each dispatch
     DevCounters* snap = nullptr;          // pinned
     hipEvent_t snapEvent = nullptr;
@@ -114,11 +115,11 @@ struct rt_ctx {
     unsigned long long snapSeg = 0, snapPaths = 0;
     int refill = 8;         // k_trace_pw: idle lanes that trigger a refill
     bool refillMkSet = false, wSetupSet = false;  // given explicitly (else by the scene's ray length, launch_pw_t)
-    int refillMk = 16;      // the same for k_trace_pw over the global queue (ten frames of the bench frame in flight: 8 -> 99.1, 16 -> 96.6, 24 -> 97.9, 32 -> 99.3 ms per step)
+    int refillMk = 16;      // the same for k_trace_pw over the global queue when set by hand ("mk_refill"); automatic: 12 for long rays, 16 otherwise (launch_pw_t)
     int chunk = 256;        // k_trace_pw: most queue entries reserved per atomic
     int ldsStackCap = 24;   // k_trace_pw: LDS stack entries per lane (8, 16 or 24); deeper BVHs use the overflow buffer
     int fastLanes = 32;     // k_trace_pw: lanes at interior nodes that skip the full vote (4K Sponza: 24 -> 32 is -2 %, 1080p: equal)
-    int wSetup = 16, wLeaf = 16; // k_trace_pw: vote weights in eighths (interior = 8); 4K Sponza: -5 % against 32 / 8
+    int wSetup = 16, wLeaf = 16; // k_trace_pw: vote weights in eighths (interior = 8); the set-up weight when set by hand ("mk_w_setup"), automatic: 32 for long rays, 16 otherwise
     int blocksPerCU = 0;    // k_trace_pw: 0 = occupancy query
     int numCUs = 256;
     int phaseStats = 0;     // diagnostic: k_trace_pw counts rounds / active lanes per phase
