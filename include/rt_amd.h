@@ -283,6 +283,14 @@ int  rt_upload_scene(rt_ctx* ctx, const RtSceneArrays* scene);
  * the texel at (u, 1 - v) of hit.uv — OBJ's v runs upwards, the image's rows downwards; with the flip dread.obj shows its
  * plate, bolts and wheels where the reference's renders/dread_texture.png has them — nearest filter, sampler
  * RenderObject.samplerIndex (0 = repeat, 1 = clamp to edge, :525-531), sRGB -> linear. Spheres are not textured.
+ * The other three slots a material carries (src/vk_engine.cpp:1109-1141: map_Ks -> metalnessIndex, map_d -> alphaIndex,
+ * map_bump -> bumpIndex) are declared likewise, all on the red channel of the texel at hit.uv (rt_det_math.h, "the other three
+ * map slots"): alpha — a triangle hit whose texel decodes below 0.5 is no hit, for every ray (inside calculateIntersections'
+ * triangle loop, raytrace.comp:305-322); metalness — the decoded texel replaces RayMaterial.reflectance (which the shader only
+ * compares with 0, :509); bump — the decoded texel is a height and the interpolated normal is tilted by the height steps to the
+ * next texel of the row and of the column along the triangle's dP/du, dP/dv (rt_bump_normal). A slot < 0 or beyond the uploaded
+ * table binds nothing. A scene that binds one of the three is rendered by the multi-kernel pipeline (k_shade_maps,
+ * k_trace_pw_alpha) whatever "pipeline" says; one whose emissive material has an alpha map traces its light queries in full.
  * Borrowed for the call; n = 0 removes all textures. */
 typedef struct RtTexture {
     uint32_t width, height;

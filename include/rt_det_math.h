@@ -303,6 +303,31 @@ RT_HD float rt_srgb8_to_linear(uint32_t byte) {
     float c = (float)byte / 255.f;
     return c <= 0.04045f ? c / 12.92f : rt_pow((c + 0.055f) / 1.055f, 2.4f);
 }
+/* The other three map slots of a material (src/vk_engine.cpp:1109-1141: map_Ks -> metalnessIndex, map_d -> alphaIndex,
+ * map_bump -> bumpIndex; the snapshot's shader reads none of them). Declared semantics, all on the RED channel of
+ * the texel at hit.uv, addressed like the albedo map:
+ *   alpha      a triangle hit whose texel decodes below 0.5 is no hit (cut-out, inside calculateIntersections' triangle loop).
+ *              rt_srgb8_to_linear is monotonic, (187) = 0.4969, (188) = 0.5029: the test is on the byte
+ *   metalness  the texel's decoded value replaces material.reflectance (which the shader only compares with 0, raytrace.comp:509)
+ *   bump       the texel's decoded value is a height; the interpolated normal is tilted by the height steps to the next texel
+ *              of the row and of the column, along the triangle's dP/du and dP/dv (rt_bump_normal) */
+#define RT_ALPHA_CUT_BYTE 188u
+/* the next texel along one axis under the object's sampler */
+RT_HD uint32_t rt_tex_next(uint32_t i, uint32_t size, bool clampToEdge) {
+    return i + 1u < size ? i + 1u : (clampToEdge ? i : 0u);
+}
+/* n: interpolated normal before the front-face sign (object space); e1 = v1 - v0, e2 = v2 - v0 and (du1, dv1), (du2, dv2) the
+ * same differences of the corners' uv; hx = h(x + 1, y) - h(x, y), hy = h(x, y + 1) - h(x, y) (rows run downwards, v upwards).
+ * Where the height field is level, and on a triangle whose uv mapping is singular, the normal stays as it is. */
+RT_HD rt_vec3 rt_bump_normal(rt_vec3 n, rt_vec3 e1, rt_vec3 e2, float du1, float dv1, float du2, float dv2, float hx, float hy) {
+    float det = du1 * dv2 - du2 * dv1;
+    if (!(rt_abs(det) > 0.f) || (hx == 0.f && hy == 0.f)) return n;
+    float r = 1.f / det;
+    rt_vec3 t = rt_scale(rt_sub(rt_scale(e1, dv2), rt_scale(e2, dv1)), r); /* dP/du */
+    rt_vec3 b = rt_scale(rt_sub(rt_scale(e2, du1), rt_scale(e1, du2)), r); /* dP/dv */
+    rt_vec3 g = rt_sub(rt_scale(rt_normalize(t), hx), rt_scale(rt_normalize(b), hy));
+    return rt_sub(rt_normalize(n), g);
+}
 
 /* ---------------------------------------------------------------- RNG (raytrace.comp:158-163) */
 RT_HD float rt_random(uint32_t* state) {

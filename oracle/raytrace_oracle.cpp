@@ -83,6 +83,23 @@ struct Scene {
     bool emitMode = false;
 };
 
+// Textures. The snapshot's shader never samples one; the semantics are declared ones (include/rt_amd.h,
+// rt_upload_textures). Parity unpinned. The table of the scene the next oracle_render calls use:
+struct OracleTexture { uint32_t width, height; std::vector<uint8_t> rgba; };
+std::vector<OracleTexture> g_textures;
+
+// the map bound to a material slot (-1 or beyond the uploaded table: none)
+const OracleTexture* mapOf(int32_t index) {
+    return (index >= 0 && (size_t)index < g_textures.size()) ? &g_textures[(size_t)index] : nullptr;
+}
+// red byte of the texel at hit.uv (+ dx texels along the row, + dy along the column, under the object's sampler)
+uint32_t mapRed8(const OracleTexture& t, const float uv[2], bool clampEdge, bool dx = false, bool dy = false) {
+    uint32_t x = rt_tex_index(uv[0], t.width, clampEdge), y = rt_tex_index(1.f - uv[1], t.height, clampEdge);
+    if (dx) x = rt_tex_next(x, t.width, clampEdge);
+    if (dy) y = rt_tex_next(y, t.height, clampEdge);
+    return t.rgba[((size_t)y * t.width + x) * 4];
+}
+
 // raytrace.comp:195-224
 HitInfo sphereIntersection(const Sphere& sphere, const Ray& ray) {
     HitInfo h;
@@ -182,6 +199,9 @@ HitInfo calculateIntersections(const Scene& sc, const Ray& ray, Tally& stats, ui
         tr.dir = rt_xform_dir(inv, ray.dir);       // not renormalised: dst stays in world units
         tr.origin = rt_xform_point(inv, ray.origin);
         rt_vec3 invDir = rt_v3(1.f / tr.dir.x, 1.f / tr.dir.y, 1.f / tr.dir.z);
+        const OracleTexture* alphaMap = g_textures.empty() ? nullptr : mapOf(sc.a.materials[object.materialIndex].alphaIndex);
+        const OracleTexture* bumpMap = g_textures.empty() ? nullptr : mapOf(sc.a.materials[object.materialIndex].bumpIndex);
+        const bool clampEdge = object.samplerIndex == 1u;
 
         uint32_t stack[128];
         uint32_t sp = 1;
@@ -195,8 +215,23 @@ HitInfo calculateIntersections(const Scene& sc, const Ray& ray, Tally& stats, ui
                     HitInfo h = triangleIntersection(tr, sc.a.triPoints[tri.v0], sc.a.triPoints[tri.v1],
                                                      sc.a.triPoints[tri.v2], tri.frontOnly != 0);
                     h.materialIndex = object.materialIndex;
+                    // alpha map (declared, rt_det_math.h): the hit is cut out where the map's texel decodes below 0.5
+                    if (alphaMap && h.didHit && h.dst < closestHit.dst && mapRed8(*alphaMap, h.uv, clampEdge) < RT_ALPHA_CUT_BYTE) h.didHit = false;
                     if (h.didHit && h.dst < closestHit.dst) {
                         closestHit = h;
+                        if (bumpMap) {  // bump map (declared, rt_bump_normal): the object-space normal tilted by the height steps
+                            const TrianglePoint &p0 = sc.a.triPoints[tri.v0], &p1 = sc.a.triPoints[tri.v1], &p2 = sc.a.triPoints[tri.v2];
+                            const float sgn = h.frontFace ? 1.f : -1.f;
+                            const float h0 = rt_srgb8_to_linear(mapRed8(*bumpMap, h.uv, clampEdge));
+                            const float hx = rt_srgb8_to_linear(mapRed8(*bumpMap, h.uv, clampEdge, true, false)) - h0;
+                            const float hy = rt_srgb8_to_linear(mapRed8(*bumpMap, h.uv, clampEdge, false, true)) - h0;
+                            const rt_vec3 q0 = rt_v3(p0.position[0], p0.position[1], p0.position[2]);
+                            const rt_vec3 e1 = rt_sub(rt_v3(p1.position[0], p1.position[1], p1.position[2]), q0);
+                            const rt_vec3 e2 = rt_sub(rt_v3(p2.position[0], p2.position[1], p2.position[2]), q0);
+                            const rt_vec3 nb = rt_bump_normal(rt_scale(h.normal, sgn), e1, e2, p1.position[3] - p0.position[3], p1.normal[3] - p0.normal[3],
+                                                              p2.position[3] - p0.position[3], p2.normal[3] - p0.normal[3], hx, hy);
+                            closestHit.normal = rt_scale(nb, sgn);
+                        }
                         // forward matrix on the normal, not the inverse transpose (:318)
                         closestHit.normal = rt_normalize(rt_xform_dir(object.transformMatrix, closestHit.normal));
                         closestHit.hitPoint = rt_xform_point(object.transformMatrix, closestHit.hitPoint);
@@ -322,11 +357,8 @@ float emitter_min_t(const Scene& sc, const Ray& ray, uint64_t& tested) {
     return tE;
 }
 
-// Textures. The snapshot's shader never samples one; this is the declared semantics of include/rt_amd.h
-// (rt_upload_textures): albedo *= texel(material.albedoIndex, hit.uv), nearest filter, sampler by object.samplerIndex
-// (0 repeat, 1 clamp to edge, src/vk_engine.cpp:525-531), R8G8B8A8_SRGB decoded to linear. Parity unpinned.
-struct OracleTexture { uint32_t width, height; std::vector<uint8_t> rgba; };
-std::vector<OracleTexture> g_textures;
+// albedo *= texel(material.albedoIndex, hit.uv), nearest filter, sampler by object.samplerIndex (0 repeat, 1 clamp to edge,
+// src/vk_engine.cpp:525-531), R8G8B8A8_SRGB decoded to linear
 bool g_cameraReuse = true;   // mirrors rt_set_tuning("camera_reuse", v): only the executed-work counters depend on it
 
 rt_vec3 albedoTexel(const Scene& sc, const HitInfo& hit, const RayMaterial& m) {
@@ -476,7 +508,12 @@ rt_vec3 trace(PathCtx& c, Ray ray, uint32_t& state, Tally& mainStats, uint32_t s
             Tally aux[3];
             HitInfo auxHit[3];
             Ray auxRay[2];
-            if (m.reflectance != 0.f) {
+            float reflectance = m.reflectance;
+            if (!hit.isSphere) {  // metalness map (declared, rt_det_math.h): the texel's decoded red replaces the material's reflectance
+                if (const OracleTexture* mt = mapOf(m.metalnessIndex))
+                    reflectance = rt_srgb8_to_linear(mapRed8(*mt, hit.uv, c.sc.a.objects[hit.objectHitIndex].samplerIndex == 1u));
+            }
+            if (reflectance != 0.f) {
                 bxdf = specularBRDF(newRay.dir, hit);
             } else if (m.ior != -1.f) {
                 bxdf = dielectricBTDF(c, newRay.dir, hit, state);
@@ -582,6 +619,7 @@ Scene make_scene(const RtSceneArrays* a, uint32_t sphereCount, uint32_t objectCo
         }
     for (uint32_t i = 0; i < a->objectCount && ok; i++) {
         if (!emissive(a->objects[i].materialIndex)) continue;
+        if (mapOf(a->materials[a->objects[i].materialIndex].alphaIndex)) { ok = false; break; }  // an emitter with holes: its list entries would need the map
         std::vector<uint32_t> st{a->objects[i].bvhIndex};
         uint64_t lo = ~0ull, hi = 0, sum = 0;
         while (!st.empty()) {

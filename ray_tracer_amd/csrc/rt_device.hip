@@ -50,7 +50,8 @@ struct rt_ctx {
     DevBuf matBuf, sphereBuf, sphereMatBuf, objInvBuf, objFwdBuf, objMetaBuf, objBoxBuf, objSkipBuf, maskBoxBuf, emitBuf, emitPreBuf;
     // host copies of what the emitter list is derived from (rebuild_emitters)
     std::vector<RayMaterial> hostMats;
-    std::vector<uint32_t> hostSphereMat, hostObjMat, hostObjRoot;
+    std::vector<uint32_t> hostSphereMat, hostObjMat, hostObjRoot, hostObjSampler;
+    DevBuf objAlphaBuf;     // per object: its material's alpha map and sampler (refresh_maps)
     // multi-GPU (rt_comm_*): this rank's RCCL communicator, a staging buffer on the gathering rank
     ncclComm_t comm = nullptr;
     int commRanks = 0, commRank = 0;
@@ -190,7 +191,10 @@ void pack_materials(const RayMaterial* m, uint32_t n, std::vector<float4>& out) 
         out[3 * i + 1] = make_float4(m[i].emissionColor[0], m[i].emissionColor[1], m[i].emissionColor[2], m[i].emissionStrength);
         float ai;
         memcpy(&ai, &m[i].albedoIndex, 4);   // bits of the int; -1 = no texture
-        out[3 * i + 2] = make_float4(m[i].ior, ai, 0.f, 0.f);
+        float mi, bi;
+        memcpy(&mi, &m[i].metalnessIndex, 4);
+        memcpy(&bi, &m[i].bumpIndex, 4);
+        out[3 * i + 2] = make_float4(m[i].ior, ai, mi, bi);
     }
 }
 
@@ -403,6 +407,35 @@ int launch_fused(rt_ctx* c, const FrameParams& fp, float4* fb) {
     return 0;
 }
 
+// k_trace_pw_alpha<PIX>: 24 stack entries in LDS and the overflow buffer behind them, object culling compiled in, no top-level
+// table — one kernel for every scene that binds an alpha map (launch_pw_t's launch, without its choices)
+int launch_pw_alpha(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
+    const bool pix = c->pixStats || ta.perRayBox;
+    int perCU = c->blocksPerCU;
+    if (perCU <= 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_trace_pw_alpha<false>, RT_BLOCK, 0) != hipSuccess || perCU <= 0)) perCU = 4;
+    const uint32_t resident = (uint32_t)perCU * (uint32_t)c->numCUs;
+    const uint32_t blocks = std::min((maxRays + RT_BLOCK - 1) / RT_BLOCK, std::max(1u, (uint32_t)((uint64_t)resident * (uint32_t)c->curGridPct / 100u)));
+    hipStream_t stream = c->curStream ? c->curStream : c->stream;
+    uint32_t* laneCounts = c->curCounts ? c->curCounts : c->q.counts;
+    uint32_t* overflow = nullptr;
+    if (c->maxLeafDepth > 24u) {
+        const size_t need = (size_t)(c->maxLeafDepth - 24u) * resident * RT_BLOCK * 4;
+        DevBuf& ob = c->curLane ? c->overflowBufSide[c->curLane - 1] : c->overflowBuf;
+        int rc = dev_alloc(c, ob, need);
+        if (rc) return rc;
+        overflow = (uint32_t*)ob.p;
+    }
+    const bool longRays = c->boxPerRay >= (double)c->fusedBelowBoxTests;
+    const uint32_t refillMk = c->refillMkSet ? (uint32_t)c->refillMk : (longRays ? 12u : 16u);
+    const uint32_t wSetup = c->wSetupSet ? (uint32_t)c->wSetup : (longRays ? 32u : 16u);
+    TracePwArgs pa{ta.queue, ta.count, laneCounts + 4, refillMk, (uint32_t)c->chunk, wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, (uint32_t)c->fastShare,
+                   ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), nullptr, overflow};
+    snprintf(c->lastKernel, sizeof c->lastKernel, "k_trace_pw_alpha<%s>", pix ? "true" : "false");
+    if (pix) hipLaunchKernelGGL((k_trace_pw_alpha<true>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
+    else hipLaunchKernelGGL((k_trace_pw_alpha<false>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
+    return 0;
+}
+
 template <int STACK>
 void launch_v0_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     uint32_t blocks = (maxRays + RT_BLOCK - 1) / RT_BLOCK;
@@ -427,7 +460,9 @@ int launch_trace(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     }
     const uint32_t d = c->maxLeafDepth;
     int rc = 0;
-    if (c->traceVariant == 0) {  // one ray per lane, whole stack in LDS
+    if (c->sc.mapFlags & RT_MAP_ALPHA) {  // a bound alpha map: the one traversal kernel that reads it (any depth, any objects)
+        rc = launch_pw_alpha(c, maxRays, ta);
+    } else if (c->traceVariant == 0) {  // one ray per lane, whole stack in LDS
         if (d <= 8) launch_v0_t<8>(c, maxRays, ta);
         else if (d <= 16) launch_v0_t<16>(c, maxRays, ta);
         else if (d <= 24) launch_v0_t<24>(c, maxRays, ta);
@@ -484,8 +519,31 @@ int harvest_events(rt_ctx* c) {
 // emissive, and the emissive spheres. "Emissive" is what lightSamplePDF asks (raytrace.comp:392): emissionStrength != 0.
 // The shortcut is only taken when it is cheap (at most RT_EMIT_MAX_TRIS triangles) and exact: the NEE term of a query that
 // is answered "not emissive" is emission * 0, which is 0 only while every material's emissionColor * emissionStrength is finite.
+// The metalness, alpha and bump maps (declared semantics, include/rt_det_math.h): which of them the uploaded scene binds at all
+// (DevScene::mapFlags — the kernels that read them are separate ones, picked by these bits), and every object's alpha map for the
+// traversal. Follows the texture table, the materials and the objects: called whenever one of the three is replaced.
+int refresh_maps(rt_ctx* c) {
+    const uint32_t n = (uint32_t)c->hostObjMat.size();
+    auto bound = [&](int32_t index) { return index >= 0 && (uint32_t)index < c->sc.texCount; };
+    uint32_t flags = 0;
+    std::vector<uint32_t> oa(std::max(n, 1u), 0xffffffffu);
+    for (uint32_t i = 0; i < n; i++) {
+        if (c->hostObjMat[i] >= c->hostMats.size()) continue;
+        const RayMaterial& m = c->hostMats[c->hostObjMat[i]];
+        if (bound(m.metalnessIndex)) flags |= RT_MAP_METALNESS;
+        if (bound(m.bumpIndex)) flags |= RT_MAP_BUMP;
+        if (bound(m.alphaIndex)) { flags |= RT_MAP_ALPHA; oa[i] = (uint32_t)m.alphaIndex | (c->hostObjSampler[i] == 1u ? 0x100u : 0u); }
+    }
+    int rc = upload(c, c->objAlphaBuf, oa.data(), oa.size() * 4);
+    if (rc) return rc;
+    c->sc.objAlpha = (const uint32_t*)c->objAlphaBuf.p;
+    c->sc.mapFlags = flags;
+    return 0;
+}
+
 int rebuild_emitters(rt_ctx* c) {
     c->sc.emitCount = 0; c->sc.emitSphereMask = 0; c->sc.emitMode = 0;
+    { int rc = refresh_maps(c); if (rc) return rc; }
     if (!c->lightQueries || c->hostMats.empty()) return 0;
     auto emissive = [&](uint32_t m) { return m < c->hostMats.size() && !(c->hostMats[m].emissionStrength == 0.f); };
     for (const RayMaterial& m : c->hostMats)
@@ -499,6 +557,7 @@ int rebuild_emitters(rt_ctx* c) {
     std::vector<uint2> list;
     for (size_t i = 0; i < c->hostObjMat.size(); i++) {
         if (!emissive(c->hostObjMat[i])) continue;
+        { const int32_t ai = c->hostMats[c->hostObjMat[i]].alphaIndex; if (ai >= 0 && (uint32_t)ai < c->sc.texCount) return 0; }  // an emitter with holes: its list entries would need the map
         const RootInfo& r = c->rootOf[c->hostObjRoot[i]];
         if (r.triTotal == 0xffffffffu || list.size() + r.triTotal > (size_t)RT_EMIT_MAX_TRIS) return 0;
         for (uint32_t t = 0; t < r.triTotal; t++) list.push_back(make_uint2((uint32_t)i, r.triFirst + t));
@@ -570,7 +629,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->sceneBufs) dev_free(b);
-    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->emitBuf, &c->emitPreBuf, &c->texelBuf, &c->texInfoBuf, &c->triUVBuf, &c->objTreeBuf, &c->objCostBuf, &c->stateBuf,
+    for (DevBuf* b : {&c->matBuf, &c->sphereBuf, &c->sphereMatBuf, &c->objInvBuf, &c->objFwdBuf, &c->objMetaBuf, &c->objBoxBuf, &c->objSkipBuf, &c->maskBoxBuf, &c->emitBuf, &c->emitPreBuf, &c->texelBuf, &c->texInfoBuf, &c->triUVBuf, &c->objTreeBuf, &c->objCostBuf, &c->objAlphaBuf, &c->stateBuf,
                       &c->queueBuf, &c->fbBuf, &c->counterBuf, &c->scratchBuf, &c->overflowBuf, &c->waveTimeBuf, &c->probeBuf})
         dev_free(*b);
     (void)rt_comm_destroy(c);
@@ -621,7 +680,7 @@ int rt_upload_textures(rt_ctx* c, const RtTexture* tex, uint32_t n) {
     c->sc.texels = (const uint32_t*)c->texelBuf.p;
     c->sc.texInfo = (const uint4*)c->texInfoBuf.p;
     c->sc.texCount = n;
-    return 0;
+    return rebuild_emitters(c);   // (which maps are bound follows the table's size; an emitter with an alpha map leaves the emitter list)
 }
 
 int rt_update_materials(rt_ctx* c, const RayMaterial* m, uint32_t n) {
@@ -837,8 +896,8 @@ int rt_update_objects(rt_ctx* c, const RenderObject* o, uint32_t n) {
     c->sc.objFwd = (const float4*)c->objFwdBuf.p;
     c->sc.objMeta = (const uint4*)c->objMetaBuf.p;
     c->sc.objectCount = n;
-    c->hostObjMat.resize(n); c->hostObjRoot.resize(n);
-    for (uint32_t i = 0; i < n; i++) { c->hostObjMat[i] = o[i].materialIndex; c->hostObjRoot[i] = o[i].bvhIndex; }
+    c->hostObjMat.resize(n); c->hostObjRoot.resize(n); c->hostObjSampler.resize(n);
+    for (uint32_t i = 0; i < n; i++) { c->hostObjMat[i] = o[i].materialIndex; c->hostObjRoot[i] = o[i].bvhIndex; c->hostObjSampler[i] = o[i].samplerIndex; }
     return rebuild_emitters(c);
 }
 
@@ -852,8 +911,9 @@ int rt_upload_scene(rt_ctx* c, const RtSceneArrays* s) {
     RT_HIP(c, hipStreamSynchronize(c->stream));
     if (c->snapPending) { c->snapBox = c->snap->boxTests; c->snapRays = c->snap->raysTraced; c->snapPending = false; }
     c->boxPerRay = -1.0;  // a new scene: its ray cost is not known yet
-    c->hostObjMat.clear(); c->hostObjRoot.clear(); c->hostSphereMat.clear(); c->hostMats.clear();
+    c->hostObjMat.clear(); c->hostObjRoot.clear(); c->hostObjSampler.clear(); c->hostSphereMat.clear(); c->hostMats.clear();
     c->sc.emitMode = 0; c->sc.emitCount = 0; c->sc.emitSphereMask = 0;
+    c->sc.mapFlags = 0;
     c->sc.texCount = 0;  // texture slots belong to the scene's materials: rt_upload_textures follows a new scene
     const uint32_t nNodes = s->bvhNodeCount, nTris = s->triangleCount;
 
@@ -1173,7 +1233,7 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
     // Both pipelines give the same bits; which one is faster depends on how much a wave has to do per pixel. Small tiles
     // and scenes with short rays (few box tests per ray, measured on this context's earlier dispatches) go to the fused one.
     poll_ray_cost(c);
-    if (c->boxPerRay < 0.0 && c->probe && !c->inProbe && (uint64_t)nPixels * fp.samples >= 8000000ull && td.debug < 0) {
+    if (c->boxPerRay < 0.0 && c->probe && !c->inProbe && !c->sc.mapFlags && (uint64_t)nPixels * fp.samples >= 8000000ull && td.debug < 0) {
         c->sc = guard.saved;
         if ((rc = probe_ray_cost(c, pc, width, height, row0, rowStride, nRows))) return rc;
         c->sc = sc;
@@ -1197,6 +1257,9 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
     const bool bigScene = (uint64_t)c->sc.nodeCount * 32u + (uint64_t)c->sc.triCount * 48u > (4ull << 20);
     const bool shortButMissing = shortRays && bigScene && c->boxPerRay >= 25.0 && nSlots >= (10u << 20);
     c->lastPipeline = c->pipeline >= 0 ? c->pipeline : (((double)nSlots < sizeLimit || (shortRays && !shortButMissing)) ? 1 : 0);
+    // a scene that binds a metalness, alpha or bump map: the kernels that read them belong to the multi-kernel pipeline
+    // (k_shade_maps, k_trace_pw_alpha), whatever "pipeline" asks for
+    if (c->sc.mapFlags) c->lastPipeline = 0;
     if (c->lastPipeline == 1) {  // wave-private fused pipeline: one launch for the whole dispatch
         rc = launch_fused(c, fp, fb);
         if (!rc && nFrames > 1u) {
@@ -1283,7 +1346,8 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
                 const uint64_t ubRays = std::min<uint64_t>((uint64_t)L.ubActive * 3, (uint64_t)L.n * 3);
                 if ((rc = launch_trace(c, (uint32_t)ubRays, ta))) break;
                 ShadeArgs sa{active[cur], L.counts + cur, active[nxt], rays[nxt], L.counts + nxt, L.counts + 2 + nxt, dc};
-                hipLaunchKernelGGL(k_shade, dim3((L.ubActive + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, L.stream, c->sc, c->ps, sa, fp);
+                if (c->sc.mapFlags & (RT_MAP_METALNESS | RT_MAP_BUMP)) hipLaunchKernelGGL(k_shade_maps, dim3((L.ubActive + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, L.stream, c->sc, c->ps, sa, fp);
+                else hipLaunchKernelGGL(k_shade, dim3((L.ubActive + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, L.stream, c->sc, c->ps, sa, fp);
                 L.cur = nxt;
                 if (L.pollPending && hipEventQuery(L.poll) == hipSuccess) {
                     L.pollPending = false;

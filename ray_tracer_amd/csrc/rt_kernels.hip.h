@@ -29,6 +29,9 @@
 
 #define RT_WAVE 64
 #ifndef RT_TE_REG
+#define RT_MAP_METALNESS 1u
+#define RT_MAP_ALPHA 2u
+#define RT_MAP_BUMP 4u
 #define RT_TE_REG 1        // trace_wave<ROOMY>: a light query's tE rides in a register instead of being re-read from the hit record when a leaf step finds a hit
 #endif
 #ifndef RT_OBJTREE
@@ -117,6 +120,11 @@ struct DevScene {
     const uint4* texInfo;
     const float4* triUV;
     uint32_t texCount;
+    // The other three map slots (declared semantics: include/rt_det_math.h). mats[3 m + 2].z / .w carry metalnessIndex / bumpIndex,
+    // objAlpha[object] the alpha map of the object's material and its sampler (slot | clamp << 8; 0xffffffff = none); mapFlags says
+    // which kinds the scene binds at all (RT_MAP_*): the kernels that read them are separate ones (k_shade_maps, k_trace_pw_alpha)
+    const uint32_t* objAlpha;
+    uint32_t mapFlags;
     float cullOriginLimit;   // rays that start farther out than this (max |origin component|) skip nothing: the padding of the world-space
                              // boxes (1e-3 of an object's size and position) only dominates the slab tests' rounding, which grows with
                              // |origin|, while the origin is within 1e3 object scales (rt_update_objects)
@@ -435,6 +443,34 @@ __device__ __forceinline__ void emitter_min_t2(const DevScene& sc, rt_vec3 ro, r
     }
 }
 
+// ---------------------------------------------------------------- the metalness / alpha / bump maps (declared: rt_det_math.h)
+// hit.uv (raytrace.comp:249-256) from a triangle hit's barycentrics, and the uv differences of the triangle's corners
+struct HitUV { float u, v, du1, dv1, du2, dv2; };
+__device__ __forceinline__ HitUV hit_uv(const DevScene& sc, uint32_t tri, float bu, float bv, float bw) {
+    const float4 a = rt_global(sc.triUV)[2 * (size_t)tri], b = rt_global(sc.triUV)[2 * (size_t)tri + 1];  // {u0 v0 u1 v1} {u2 v2}
+    HitUV r;
+    r.u = (bw * a.x + bu * a.z) + bv * b.x;
+    r.v = (bw * a.y + bu * a.w) + bv * b.y;
+    if ((a.x == a.z && a.y == a.w) || (a.z == b.x && a.w == b.y) || (b.x == a.x && b.y == a.y)) { r.u = 0.5f; r.v = 0.5f; }
+    r.du1 = a.z - a.x; r.dv1 = a.w - a.y; r.du2 = b.x - a.x; r.dv2 = b.y - a.y;
+    return r;
+}
+// red byte of map `slot`'s texel at (u, 1 - v), or of the next one along the row (dx) / the column (dy), under the object's sampler
+__device__ __forceinline__ uint32_t map_red8(const DevScene& sc, uint32_t slot, bool clampEdge, float u, float v, bool dx, bool dy) {
+    const uint4 ti = rt_global(sc.texInfo)[slot];
+    uint32_t x = rt_tex_index(u, ti.y, clampEdge), y = rt_tex_index(1.f - v, ti.z, clampEdge);
+    if (dx) x = rt_tex_next(x, ti.y, clampEdge);
+    if (dy) y = rt_tex_next(y, ti.z, clampEdge);
+    return rt_global(sc.texels)[(size_t)ti.x + (size_t)y * ti.y + x] & 0xffu;
+}
+// alpha map: is this triangle hit cut out? (trace_wave<ALPHA>, leaf step; objAlpha: DevScene)
+__device__ __forceinline__ bool alpha_cut(const DevScene& sc, uint32_t obj, uint32_t tri, const TriHit& h) {
+    const uint32_t oa = rt_global(sc.objAlpha)[obj];
+    if ((oa & 0xffu) >= sc.texCount) return false;   // (0xffffffff: no map)
+    const HitUV q = hit_uv(sc, tri, h.u, h.v, h.w);
+    return map_red8(sc, oa & 0xffu, (oa & 0x100u) != 0u, q.u, q.v, false, false) < RT_ALPHA_CUT_BYTE;
+}
+
 // DevScene::emitPre from the listed triangles' positions: tri_intersect's first lines (raytrace.comp:228-231), same operations
 __global__ void k_emit_precompute(const float4* __restrict__ triPos, const uint2* __restrict__ emitTris, uint32_t n, float4* __restrict__ out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -660,7 +696,8 @@ struct WaveTotals {
 // ROOMY: the kernel is built for five work-groups per CU (96 registers per lane): a light query's tE rides in a register there
 // (-2 % on the bench frame). With the 80 registers of six work-groups per CU, and in the fused kernel, one more live register
 // means one more spill: measured there, it loses (Cornell + bunny +3 %, C5 at 4K +1 %).
-template <int STACK, bool OVF, bool PIX, bool STATS, bool LOCAL, bool CULL, int HOT = 0, bool ROOMY = false>
+// ALPHA: triangle hits are looked up in their object's alpha map before they count (alpha_cut; k_trace_pw_alpha only).
+template <int STACK, bool OVF, bool PIX, bool STATS, bool LOCAL, bool CULL, int HOT = 0, bool ROOMY = false, bool ALPHA = false>
 __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& ps, const TracePwArgs& ta, uint32_t* stack, uint32_t* ovf,
                                            size_t ovfStride, const uint32_t* localList, uint32_t n, WaveTotals& wt, const uint2* metaLds,
                                            const float4* hotLds = nullptr) {
@@ -805,16 +842,16 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                         if (STATS) RT_STAMP_AFTER_LOADS(wt.dbgLoad[3], tLeaf);
                         const rt_vec3 o = rt_v3(troXY.x, troXY.y, zOI.x);
                         const TriHit h0 = tri_intersect(o, trd, rt_v3(a0.x, a0.y, a0.z), rt_v3(b0.x, b0.y, b0.z), rt_v3(c0.x, c0.y, c0.z), __float_as_uint(a0.w) != 0u);
-                        if (h0.didHit && h0.dst < best) { best = h0.dst; bestObj = cur_object(); bestTri = j; closer = true; }
+                        if (h0.didHit && h0.dst < best && !(ALPHA && alpha_cut(sc, cur_object(), j, h0))) { best = h0.dst; bestObj = cur_object(); bestTri = j; closer = true; }
                         if (j1 != j) {
                             const TriHit h1 = tri_intersect(o, trd, rt_v3(a1.x, a1.y, a1.z), rt_v3(b1.x, b1.y, b1.z), rt_v3(c1.x, c1.y, c1.z), __float_as_uint(a1.w) != 0u);
-                            if (h1.didHit && h1.dst < best) { best = h1.dst; bestObj = cur_object(); bestTri = j1; closer = true; }
+                            if (h1.didHit && h1.dst < best && !(ALPHA && alpha_cut(sc, cur_object(), j1, h1))) { best = h1.dst; bestObj = cur_object(); bestTri = j1; closer = true; }
                         }
                     } else {
                         for (; j < jEnd; j++) {
                             const float4 a = sc.triPos[3 * (size_t)j], b = sc.triPos[3 * (size_t)j + 1], c = sc.triPos[3 * (size_t)j + 2];
                             const TriHit h = tri_intersect(rt_v3(troXY.x, troXY.y, zOI.x), trd, f4xyz(a), f4xyz(b), f4xyz(c), __float_as_uint(a.w) != 0u);
-                            if (h.didHit && h.dst < best) { best = h.dst; bestObj = cur_object(); bestTri = j; closer = true; }
+                            if (h.didHit && h.dst < best && !(ALPHA && alpha_cut(sc, cur_object(), j, h))) { best = h.dst; bestObj = cur_object(); bestTri = j; closer = true; }
                         }
                     }
                     // Light queries carry tE, the distance of the nearest emissive primitive they hit at all (emitter_min_t2; 0 for
@@ -1032,8 +1069,8 @@ __device__ __forceinline__ void fill_meta_lds(const DevScene& sc, uint2* s_meta)
 
 // HOT > 0: the first HOT child pairs of the device numbering (the meshes' top levels, DevScene::hotNodes) are served from a copy
 // in LDS (64 B each); BLOCKS = work-groups per CU the kernel is built for (what the LDS of stack + table leaves room for)
-template <int STACK, bool OVF, bool PIX, bool STATS, bool CULL, int HOT = 0, int BLOCKS = 6>
-__global__ __launch_bounds__(RT_BLOCK, BLOCKS) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
+template <int STACK, bool OVF, bool PIX, bool STATS, bool CULL, int HOT, bool ROOMY, bool ALPHA>
+__device__ __forceinline__ void trace_pw_block(const DevScene& sc, const PathState& ps, const TracePwArgs& ta) {
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * (STACK + 1) * RT_WAVE];  // +1: pushes are unconditional
     __shared__ uint2 s_meta[RT_META_LDS];
     __shared__ float4 s_hot[HOT ? 4 * HOT : 1];
@@ -1045,7 +1082,7 @@ __global__ __launch_bounds__(RT_BLOCK, BLOCKS) void k_trace_pw(DevScene sc, Path
     const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
     WaveTotals wt;
     const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
-    trace_wave<STACK, OVF, PIX, STATS, false, CULL, HOT, BLOCKS == 5>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt, s_meta, s_hot);
+    trace_wave<STACK, OVF, PIX, STATS, false, CULL, HOT, ROOMY, ALPHA>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt, s_meta, s_hot);
 
     const uint32_t skipTrips = STATS ? wave_sum_u32(wt.dbgWait[3]) : 0u;
     if (STATS && lane_id() == 0) {
@@ -1075,6 +1112,18 @@ __global__ __launch_bounds__(RT_BLOCK, BLOCKS) void k_trace_pw(DevScene sc, Path
     }
 }
 
+template <int STACK, bool OVF, bool PIX, bool STATS, bool CULL, int HOT = 0, int BLOCKS = 6>
+__global__ __launch_bounds__(RT_BLOCK, BLOCKS) void k_trace_pw(DevScene sc, PathState ps, TracePwArgs ta) {
+    trace_pw_block<STACK, OVF, PIX, STATS, CULL, HOT, BLOCKS == 5, false>(sc, ps, ta);
+}
+// The traversal of a scene that binds an alpha map (DevScene::mapFlags & RT_MAP_ALPHA): one configuration for every such scene —
+// 24 stack entries in LDS with the overflow buffer behind them, object culling compiled in, no top-level table, four work-groups
+// per CU (128 registers: the texel look-up of a hit candidate sits in the leaf step)
+template <bool PIX>
+__global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_pw_alpha(DevScene sc, PathState ps, TracePwArgs ta) {
+    trace_pw_block<24, true, PIX, false, true, 0, true, true>(sc, ps, ta);
+}
+
 // ---------------------------------------------------------------- hit reconstruction
 // The trace kernel stores only (dst, object, triangle). Everything else of the
 // shader's HitInfo is recomputed here with the same operations the traversal
@@ -1084,6 +1133,7 @@ struct FullHit {
     rt_vec3 hitPoint, normal;
     uint32_t materialIndex;
     bool frontFace;
+    float u, v;   // hit.uv of a triangle hit (reconstruct_hit<MAPS> only)
 };
 
 // hit.uv (raytrace.comp:249-256) and the albedo texel at (u, 1 - v); the declared texture semantics of include/rt_amd.h
@@ -1107,8 +1157,11 @@ __device__ __forceinline__ rt_vec3 albedo_texel(const DevScene& sc, uint32_t slo
     return rt_v3(rt_srgb8_to_linear(t & 0xffu), rt_srgb8_to_linear((t >> 8) & 0xffu), rt_srgb8_to_linear((t >> 16) & 0xffu));
 }
 
+// MAPS (k_shade_maps): the object's bump map tilts the interpolated normal (rt_bump_normal), and the hit's uv is handed on
+template <bool MAPS = false>
 __device__ __forceinline__ FullHit reconstruct_hit(const DevScene& sc, rt_vec3 ro, rt_vec3 rd, uint32_t obj, uint32_t tri) {
     FullHit f;
+    f.u = 0.f; f.v = 0.f;
     if (obj & RT_HIT_SPHERE) {
         uint32_t i = obj & ~RT_HIT_SPHERE;
         float4 s = rt_global(sc.spheres)[i];
@@ -1139,6 +1192,18 @@ __device__ __forceinline__ FullHit reconstruct_hit(const DevScene& sc, rt_vec3 r
     const float4* tn = rt_global(sc.triNrm) + 3 * (size_t)tri;
     rt_vec3 n0 = f4xyz(tn[0]), n1 = f4xyz(tn[1]), n2 = f4xyz(tn[2]);
     rt_vec3 ni = rt_add(rt_add(rt_scale(n0, h.w), rt_scale(n1, h.u)), rt_scale(n2, h.v));
+    if (MAPS) {
+        const HitUV q = hit_uv(sc, tri, h.u, h.v, h.w);
+        f.u = q.u; f.v = q.v;
+        const uint32_t bumpSlot = __float_as_uint(rt_global(sc.mats)[3 * meta.z + 2].w);   // bumpIndex; 0xffffffff (-1) = none
+        if (bumpSlot < sc.texCount) {
+            const bool clampEdge = ((meta.w >> 16) & 0xffffu) == 1u;
+            const float h0 = rt_srgb8_to_linear(map_red8(sc, bumpSlot, clampEdge, q.u, q.v, false, false));
+            const float hx = rt_srgb8_to_linear(map_red8(sc, bumpSlot, clampEdge, q.u, q.v, true, false)) - h0;
+            const float hy = rt_srgb8_to_linear(map_red8(sc, bumpSlot, clampEdge, q.u, q.v, false, true)) - h0;
+            ni = rt_bump_normal(ni, rt_sub(f4xyz(b), f4xyz(a)), rt_sub(f4xyz(c), f4xyz(a)), q.du1, q.dv1, q.du2, q.dv2, hx, hy);
+        }
+    }
     ni = rt_scale(ni, h.frontFace ? 1.f : -1.f);
     rt_vec3 op = rt_add(tro, rt_scale(trd, h.dst));
     if (ident && vec_is_plain(ni) && vec_is_plain(op)) {
@@ -1288,6 +1353,8 @@ struct ShadeArgs {
 // of this diffuse bounce have to be traced — a light query that emitter_min_t2 answers is not; bit 2: the main ray needs no
 // traversal, its hit record is already there: the kept camera hit), refRays (the shader's
 // calculateIntersections calls for this segment), nPaths (1 if a sample finished), emitTests (primitives emitter_min_t2 tested).
+// MAPS (k_shade_maps): the scene binds a metalness or a bump map
+template <bool MAPS = false>
 __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& ps, const FrameParams& fp, uint32_t slot, bool& alive,
                                            uint32_t& auxMask, uint32_t& refRays, uint32_t& nPaths, uint32_t& emitTests, bool withMask = true) {
     bool wantAux = false;  // a diffuse bounce whose MIS the next segment finishes (raytrace.comp:443-460)
@@ -1349,9 +1416,14 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
             misW = misWeight2;
         }
 
-        FullHit hit = reconstruct_hit(sc, ro, rd, obj, hitTriIdx);
+        FullHit hit = reconstruct_hit<MAPS>(sc, ro, rd, obj, hitTriIdx);
         const float4* mp = rt_global(sc.mats) + 3 * hit.materialIndex;
         float4 mA = mp[0], mE = mp[1], mI = mp[2];
+        if (MAPS) {  // metalness map: the texel's decoded red replaces the material's reflectance (triangle hits)
+            const uint32_t metalSlot = __float_as_uint(mI.z);   // metalnessIndex; 0xffffffff (-1) = none
+            if (metalSlot < sc.texCount && !(obj & RT_HIT_SPHERE))
+                mA.w = rt_srgb8_to_linear(map_red8(sc, metalSlot, ((rt_global(sc.objMeta)[obj].w >> 16) & 0xffffu) == 1u, hit.u, hit.v, false, false));
+        }
 
         // 0-1 NEE (:501-505)
         rt_vec3 emission = rt_scale(rt_v3(mE.x, mE.y, mE.z), mE.w);
@@ -1520,7 +1592,8 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
     }
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, ShadeArgs sa, FrameParams fp) {
+template <bool MAPS>
+__device__ __forceinline__ void shade_block(const DevScene& sc, const PathState& ps, const ShadeArgs& sa, const FrameParams& fp) {
     __shared__ uint32_t s_cnt[RT_BLOCK / RT_WAVE][6];  // per wave: alive, aux rays, refRays, paths, segments, emitter tests
     __shared__ uint32_t s_base[2];
     const uint32_t n = *sa.inCount;
@@ -1536,7 +1609,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
     if (live) {
         slot = sa.inActive[gid];
         path = slot != 0xffffffffu;  // RT_QUEUE_HOLE
-        if (path) shade_path(sc, ps, fp, slot, alive, auxMask, refRays, nPaths, emitTests);
+        if (path) shade_path<MAPS>(sc, ps, fp, slot, alive, auxMask, refRays, nPaths, emitTests);
     }
 
     // Queue compaction: ranks inside a wave from ballots, wave offsets through LDS, and ONE atomic
@@ -1572,6 +1645,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, S
         if (auxMask & 2u) sa.outRays[baseR + nM + nL + lanes_below(mC)] = (slot << 2) | RAY_PROBE;
     }
 }
+
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DevScene sc, PathState ps, ShadeArgs sa, FrameParams fp) { shade_block<false>(sc, ps, sa, fp); }
+// the same for a scene that binds a metalness or a bump map (DevScene::mapFlags)
+__global__ __launch_bounds__(RT_BLOCK) void k_shade_maps(DevScene sc, PathState ps, ShadeArgs sa, FrameParams fp) { shade_block<true>(sc, ps, sa, fp); }
 
 // ---------------------------------------------------------------- k_resolve
 // raytrace.comp:574-593. `rgba` holds the previous frame when progressive
@@ -1828,7 +1905,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_hit_details(DevScene sc, PathState
     h.boxTests = perRayBox[i];
     h.triTests = perRayTri[i];
     if (obj != RT_HIT_NONE) {
-        FullHit f = reconstruct_hit(sc, f4xyz(ps.rayO()[i]), f4xyz(ps.rayD()[i]), obj, tri);
+        FullHit f = reconstruct_hit<true>(sc, f4xyz(ps.rayO()[i]), f4xyz(ps.rayD()[i]), obj, tri);
         h.didHit = 1;
         h.isSphere = (obj & RT_HIT_SPHERE) ? 1u : 0u;
         h.objectHitIndex = obj & ~RT_HIT_SPHERE;

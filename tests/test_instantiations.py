@@ -27,7 +27,7 @@ UNREACHED_ON_PURPOSE = {"k_trace<64>"}
 
 def library_instantiations():
     out = subprocess.run(["nm", "-C", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    return set(re.findall(r"__device_stub__(k_(?:trace_pw|render_fused|trace)<[^>]*>)", out))
+    return set(re.findall(r"__device_stub__(k_(?:trace_pw_alpha|trace_pw|render_fused|trace)<[^>]*>)", out))
 
 
 def _normals(tri):
@@ -80,6 +80,7 @@ def build_scene(mesh, placed):
         t2, n2 = soup(40, 77, 0.1)
         s.add_mesh("placed_a", t2, n2, engine.placement(position=(0.5, 0.1, 0.2), rotation=(20, 35, 10), scale=(0.4, 0.5, 0.4)), mirror)
         s.add_mesh("placed_b", t2, n2, engine.placement(position=(-0.5, 0.0, -0.1), rotation=(-15, 70, 5), scale=(0.5, 0.4, 0.6)), grey)
+    s.grey = grey
     return s, depth
 
 
@@ -142,6 +143,18 @@ def test_every_instantiation_in_the_library_against_the_oracle(renderer):
                     run(f"fused lds_stack={cap}", pipeline=1, lds_stack=cap)
                     run(f"fused heat map lds_stack={cap}", dbg=True, pipeline=1, lds_stack=cap)
                 run("one ray per lane", pipeline=0, trace_variant=0)
+                if name == "d13":
+                    # k_trace_pw_alpha<PIX>, the traversal of scenes that bind an alpha map (tests/test_textures.py has its real cases):
+                    # the meshes here carry no uvs, so every hit looks up the map's one texel at (0.5, 0.5) — opaque: the same frame
+                    m = s.material(s.grey); m.alphaIndex = 0; s.set_material(s.grey, m)
+                    opaque = [np.full((2, 2, 4), 255, np.uint8)]
+                    renderer.upload_scene(s); renderer.upload_textures(opaque); pyoracle.set_textures(opaque)
+                    try:
+                        for dbg in (False, True):
+                            refs[dbg] = pyoracle.render(s, pcs[dbg], W, H)
+                            run("alpha map", dbg=dbg)
+                    finally:
+                        renderer.upload_textures([]); pyoracle.set_textures([])
     finally:
         for k in knobs:
             renderer.set_tuning(k, {"pipeline": -1, "hot_pairs": 2, "lds_stack": 24, "phase_stats": 0, "trace_variant": 1}[k])
