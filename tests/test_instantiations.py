@@ -3,9 +3,9 @@
 The traversal is one device function (trace_wave) compiled into ~80 kernels: k_trace_pw<STACK, OVF, PIX, STATS, CULL, HOT, BLOCKS>,
 k_render_fused<STACK, OVF, PIX, CULL> and the one-ray-per-lane k_trace<STACK>. Which one runs follows from the scene (deepest
 leaf, placed objects), the dispatch (heat maps) and knobs — so the other parity tests cover whatever their scenes happen to
-select. Rounds 2 and 3 met two passes of ROCm 7.2.0's AMDGPU backend (si-optimize-exec-masking-pre-ra, si-opt-vgpr-liverange)
-that each miscompiled ONE heavily spilling instantiation of k_render_fused while all others stayed right, and the library is
-built with both off (__graft_entry__.HIPFLAGS; tools/miscompile_repro.sh). This test is the guard for that decision — on the
+select. Rounds 2 and 3 met three wrong binaries of heavily spilling k_render_fused instantiations (all others stayed right) under
+ROCm 7.2.0's AMDGPU backend; the pass they have in common is si-opt-vgpr-liverange (tools/pass_attribution.sh) and the library is
+built with it off (__graft_entry__.HIPFLAGS; tools/miscompile_repro.sh). This test is the guard for that decision — on the
 library built with si-opt-vgpr-liverange left on it fails —: it reads the list of instantiations out of the built library (host stubs in its symbol table), forces
 each of them through scenes of the right BVH depth, with and without placed objects, heat maps, phase statistics, the three
 top-level-table modes and the LDS stack caps, asks the library which kernel it launched (rt_last_kernel), compares pixels and
