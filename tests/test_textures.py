@@ -289,7 +289,7 @@ def _map_set(seed=5):
 KEYS = ("boxTests", "triTests", "raysTraced", "raysHit", "raysReference", "paths", "segments", "emitterTests")
 
 
-def _same_as_oracle(renderer, s, tex, pc, W, H, what, kernel=None):
+def _same_as_oracle(renderer, s, tex, pc, W, H, what, kernel=None, maps=True):
     renderer.upload_scene(s.scene)
     s.push(renderer, "objects")
     s.push(renderer, "materials")
@@ -302,7 +302,7 @@ def _same_as_oracle(renderer, s, tex, pc, W, H, what, kernel=None):
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), f"{what}: pixels differ from the oracle's ({renderer.last_kernel()})"
     assert {k: cnt[k] for k in KEYS} == {k: rc[k] for k in KEYS}, what
     assert rc["lightQueryMismatch"] == 0
-    assert renderer.last_pipeline() == 0, "scenes that bind these maps belong to the multi-kernel pipeline"
+    assert not maps or renderer.last_pipeline() == 0, "scenes that bind these maps belong to the multi-kernel pipeline"
     if kernel:
         assert renderer.last_kernel() == kernel, (what, renderer.last_kernel())
     return img
@@ -329,6 +329,13 @@ def test_metalness_alpha_bump_maps_against_the_oracle(renderer, tmp_path):
                     if n <= 5:   # and the maps are really in the picture
                         renderer.upload_textures(tex[:1])
                         assert not np.array_equal(renderer.render(pc, W, H), img), slots
+        # slots beyond the uploaded table bind nothing (the ordinary kernels run); one-texel maps; a map narrower than two texels
+        s = _bound(tmp_path / "x1", 1, 2.5, alphaIndex=7, metalnessIndex=5, bumpIndex=63)
+        _same_as_oracle(renderer, s, tex, pc, W, H, "slots out of range", maps=False)
+        assert "alpha" not in renderer.last_kernel()
+        tiny = [tex[0], _grey(1, 1, 200), _grey(1, 1, 90), _grey(1, 3, np.array([[10], [120], [250]]))]
+        _same_as_oracle(renderer, _bound(tmp_path / "x2", 0, 2.5, alphaIndex=1, metalnessIndex=2, bumpIndex=3), tiny, pc, W, H, "one-texel maps", "k_trace_pw_alpha<false>")
+        _same_as_oracle(renderer, _bound(tmp_path / "x3", 1, 2.5, alphaIndex=1, metalnessIndex=2, bumpIndex=3), tiny, pc, W, H, "one-texel maps, clamped")
         full = dict(alphaIndex=1, metalnessIndex=2, bumpIndex=3)
         # "pipeline" 1 is overruled; heat maps count per pixel through k_trace_pw_alpha<true>
         renderer.set_tuning("pipeline", 1)
