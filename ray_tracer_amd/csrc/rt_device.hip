@@ -280,7 +280,7 @@ int launch_pw_t(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     const uint32_t refillMk = c->refillMkSet ? (uint32_t)c->refillMk : (longRays ? 12u : 16u);
     const uint32_t wSetup = c->wSetupSet ? (uint32_t)c->wSetup : (longRays ? 32u : 16u);
     TracePwArgs pa{ta.queue, ta.count, laneCounts + 4, refillMk, (uint32_t)c->chunk, wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, (uint32_t)c->fastShare,
-                   ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), waveTimes, overflow};
+                   ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), waveTimes, overflow, ta.countAux, ta.countAux2, ta.auxOffset};
     {
         const bool stats = hotMode == 0 && c->phaseStats, px = hotMode == 0 && (c->phaseStats || pix);
         snprintf(c->lastKernel, sizeof c->lastKernel, "k_trace_pw<%d, %s, %s, %s, %s, %d, %d>", STACK, OVF ? "true" : "false", px ? "true" : "false",
@@ -429,7 +429,7 @@ int launch_pw_alpha(rt_ctx* c, uint32_t maxRays, const TraceArgs& ta) {
     const uint32_t refillMk = c->refillMkSet ? (uint32_t)c->refillMk : (longRays ? 12u : 16u);
     const uint32_t wSetup = c->wSetupSet ? (uint32_t)c->wSetup : (longRays ? 32u : 16u);
     TracePwArgs pa{ta.queue, ta.count, laneCounts + 4, refillMk, (uint32_t)c->chunk, wSetup, (uint32_t)c->wLeaf, (uint32_t)c->fastLanes, (uint32_t)c->fastShare,
-                   ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), nullptr, overflow};
+                   ta.perRayBox, ta.perRayTri, ta.counters, (unsigned long long*)((char*)c->counterBuf.p + sizeof(DevCounters)), nullptr, overflow, ta.countAux, ta.countAux2, ta.auxOffset};
     snprintf(c->lastKernel, sizeof c->lastKernel, "k_trace_pw_alpha<%s>", pix ? "true" : "false");
     if (pix) hipLaunchKernelGGL((k_trace_pw_alpha<true>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
     else hipLaunchKernelGGL((k_trace_pw_alpha<false>), dim3(blocks), dim3(RT_BLOCK), 0, stream, c->sc, c->ps, pa);
@@ -1301,7 +1301,7 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
         for (int l = 0; l < nLanes; l++) {
             const uint32_t u = units / (uint32_t)nLanes + ((uint32_t)l < units % (uint32_t)nLanes ? 1u : 0u);
             const uint32_t end = std::min(nSlots, at + u * unit);
-            lane[l] = Lane{l ? c->sideStream[l - 1] : c->stream, counts + 8 * l, l ? c->pollEventSide[l - 1] : c->pollEvent, at, end - at, end - at, 0, false, end == at};
+            lane[l] = Lane{l ? c->sideStream[l - 1] : c->stream, counts + 16 * l, l ? c->pollEventSide[l - 1] : c->pollEvent, at, end - at, end - at, 0, false, end == at};
             at = end;
         }
     }
@@ -1310,7 +1310,7 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
         if (!L.n) continue;
         hipLaunchKernelGGL(k_raygen, dim3((L.n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->sc, c->ps,
                            c->q.active[0] + L.begin, c->q.rays[0] + 3 * (size_t)L.begin, fp, L.begin, L.begin + L.n);
-        // counts: [0],[1] active paths of buffer 0/1; [2],[3] rays of buffer 0/1; [4] the traversal's work counter
+        // counts: [0],[1] active paths of buffer 0/1; [2],[3] main rays of buffer 0/1; [4] the traversal's work counter; [5],[6] NEE rays, [7],[8] cosine probes of buffer 0/1
         if (fp.samples > 0) hipLaunchKernelGGL(k_init_counts, dim3(1), dim3(64), 0, c->stream, L.counts, L.n);
     }
     RT_HIP(c, hipGetLastError());
@@ -1341,11 +1341,11 @@ int render_impl(rt_ctx* c, const PushConstants* pc, uint32_t width, uint32_t hei
                 const int cur = L.cur, nxt = cur ^ 1;
                 uint32_t* const active[2] = {c->q.active[0] + L.begin, c->q.active[1] + L.begin};
                 uint32_t* const rays[2] = {c->q.rays[0] + 3 * (size_t)L.begin, c->q.rays[1] + 3 * (size_t)L.begin};
-                hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, L.stream, L.counts + nxt, L.counts + 2 + nxt, L.counts + 4);
-                TraceArgs ta{rays[cur], L.counts + 2 + cur, nullptr, nullptr, dc};
+                hipLaunchKernelGGL(k_zero_counts, dim3(1), dim3(64), 0, L.stream, L.counts + nxt, L.counts + 2 + nxt, L.counts + 4, L.counts + 5 + nxt, L.counts + 7 + nxt);
+                TraceArgs ta{rays[cur], L.counts + 2 + cur, nullptr, nullptr, dc, L.counts + 5 + cur, L.counts + 7 + cur, L.n};
                 const uint64_t ubRays = std::min<uint64_t>((uint64_t)L.ubActive * 3, (uint64_t)L.n * 3);
                 if ((rc = launch_trace(c, (uint32_t)ubRays, ta))) break;
-                ShadeArgs sa{active[cur], L.counts + cur, active[nxt], rays[nxt], L.counts + nxt, L.counts + 2 + nxt, dc};
+                ShadeArgs sa{active[cur], L.counts + cur, active[nxt], rays[nxt], L.counts + nxt, L.counts + 2 + nxt, dc, L.counts + 5 + nxt, L.counts + 7 + nxt, L.n};
                 if (c->sc.mapFlags & (RT_MAP_METALNESS | RT_MAP_BUMP)) hipLaunchKernelGGL(k_shade_maps, dim3((L.ubActive + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, L.stream, c->sc, c->ps, sa, fp);
                 else hipLaunchKernelGGL(k_shade, dim3((L.ubActive + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, L.stream, c->sc, c->ps, sa, fp);
                 L.cur = nxt;

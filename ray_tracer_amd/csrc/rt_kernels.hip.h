@@ -32,6 +32,9 @@
 #define RT_MAP_METALNESS 1u
 #define RT_MAP_ALPHA 2u
 #define RT_MAP_BUMP 4u
+#ifndef RT_QUEUE_ORDER
+#define RT_QUEUE_ORDER 0   // k_shade: the ray queue's pieces are {main, NEE, cosine probes} (1: {main, cosine probes, NEE})
+#endif
 #define RT_TE_REG 1        // trace_wave<ROOMY>: a light query's tE rides in a register instead of being re-read from the hit record when a leaf step finds a hit
 #endif
 #ifndef RT_OBJTREE
@@ -508,14 +511,26 @@ struct TraceArgs {
     uint32_t* perRayBox;      // optional per-ray stats (rt_trace_rays), indexed by gid
     uint32_t* perRayTri;
     DevCounters* counters;
+    // the queue in three pieces (k_shade): `*count` main rays at queue[0 ..], `*countAux` rays of the second kind at
+    // queue[auxOffset ..], `*countAux2` of the third at queue[2 * auxOffset ..]: a wave's rays are of one kind (coherent), and the
+    // long ones are dealt first, so that a launch's tail is made of the short ones. NULL: one piece.
+    const uint32_t* countAux;
+    const uint32_t* countAux2;
+    uint32_t auxOffset;
 };
+// queue position of the i-th ray of a launch
+__device__ __forceinline__ uint32_t queue_pos(uint32_t i, uint32_t n0, uint32_t n1, uint32_t off) {
+    return i < n0 ? i : (i < n0 + n1 ? i - n0 + off : i - n0 - n1 + 2u * off);
+}
 
 template <int STACK>
 __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, TraceArgs ta) {
     __shared__ uint32_t s_stack[(RT_BLOCK / RT_WAVE) * STACK * RT_WAVE];
-    const uint32_t n = *ta.count;
+    const uint32_t nMain = *ta.count, nAux = ta.countAux ? *ta.countAux : 0u;
+    const uint32_t n = nMain + nAux + (ta.countAux ? *ta.countAux2 : 0u);
     const uint32_t gid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const bool live = gid < n && !(ta.queue && ta.queue[gid] == 0xffffffffu);  // RT_QUEUE_HOLE
+    const uint32_t qpos = queue_pos(gid, nMain, nAux, ta.auxOffset);
+    const bool live = gid < n && !(ta.queue && ta.queue[qpos] == 0xffffffffu);  // RT_QUEUE_HOLE
     if (__ballot(live) == 0ull) return;
 
     uint32_t* stack = s_stack + (threadIdx.x / RT_WAVE) * STACK * RT_WAVE + (threadIdx.x & (RT_WAVE - 1));
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(DevScene sc, PathState ps, T
     uint32_t didHit = 0;
     uint32_t slot = 0, kind = RAY_MAIN;
     if (live) {
-        uint32_t id = ta.queue ? ta.queue[gid] : (gid << 2);
+        uint32_t id = ta.queue ? ta.queue[qpos] : (gid << 2);
         slot = id >> 2;
         kind = id & 3u;
         rt_vec3 ro, rd;
@@ -664,6 +679,9 @@ struct TracePwArgs {
     unsigned long long* phaseStats;  // STATS only: [8] rounds and active lanes per phase
     unsigned long long* waveTimes;   // STATS only: wall_clock64() at start and end of every wave (2 per wave)
     uint32_t* overflow;       // OVF only: stack entries beyond STACK, (maxDepth - STACK) x resident lanes
+    const uint32_t* countAux; // the queue's second and third piece (TraceArgs)
+    const uint32_t* countAux2;
+    uint32_t auxOffset;
 };
 
 // STATS: wait for every outstanding load, then read the clock (splits a step's time into "data on its way" and the rest)
@@ -720,6 +738,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
     uint32_t nextChunk = LOCAL ? 0u : min(ta.chunk, max(16u, n / (2u * gridDim.x * (RT_BLOCK / RT_WAVE))));
 
     uint32_t thr = ta.fastLanes;
+    const uint32_t nMain = LOCAL ? 0u : *ta.count, nAux = (LOCAL || !ta.countAux) ? 0u : *ta.countAux;   // the queue's pieces (TraceArgs::countAux)
 
     uint32_t reach = 0xffffffffu;  // objects (of the mask's window) the ray has to enter, from its creator (sphere_seed)
     float earlyT = 0.f;            // light queries: tE, the distance of the nearest emissive primitive on the ray (0: any other ray)
@@ -789,7 +808,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, const PathState& 
                     const uint32_t rk = lanes_below(mIdle);
                     if (rk < take) {
                         qidx = resBase + rk;
-                        id = LOCAL ? localList[qidx] : (ta.queue ? ta.queue[qidx] : (qidx << 2));
+                        id = LOCAL ? localList[qidx] : (ta.queue ? ta.queue[queue_pos(qidx, nMain, nAux, ta.auxOffset)] : (qidx << 2));
                         cur = (!LOCAL && id == 0xffffffffu) ? RT_CUR_IDLE : RT_CUR_INIT;  // RT_QUEUE_HOLE: no ray behind this entry (k_raygen)
                     }
                 }
@@ -1082,7 +1101,7 @@ __device__ __forceinline__ void trace_pw_block(const DevScene& sc, const PathSta
     const size_t ovfStride = (size_t)gridDim.x * RT_BLOCK;
     WaveTotals wt;
     const unsigned long long tStart = STATS ? wall_clock64() : 0ull;
-    trace_wave<STACK, OVF, PIX, STATS, false, CULL, HOT, ROOMY, ALPHA>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count, wt, s_meta, s_hot);
+    trace_wave<STACK, OVF, PIX, STATS, false, CULL, HOT, ROOMY, ALPHA>(sc, ps, ta, stack, ovf, ovfStride, nullptr, *ta.count + (ta.countAux ? *ta.countAux + *ta.countAux2 : 0u), wt, s_meta, s_hot);
 
     const uint32_t skipTrips = STATS ? wave_sum_u32(wt.dbgWait[3]) : 0u;
     if (STATS && lane_id() == 0) {
@@ -1345,6 +1364,9 @@ struct ShadeArgs {
     uint32_t* outActiveCount;
     uint32_t* outRayCount;
     DevCounters* counters;
+    uint32_t* outAuxCount;    // the queue's second and third piece, outRays[auxOffset ..] and outRays[2 * auxOffset ..] (TraceArgs::countAux)
+    uint32_t* outAuxCount2;
+    uint32_t auxOffset;
 };
 
 // One path, one segment: trace()'s loop body (raytrace.comp:495-534) with diffuseBRDF split around the
@@ -1594,8 +1616,8 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
 
 template <bool MAPS>
 __device__ __forceinline__ void shade_block(const DevScene& sc, const PathState& ps, const ShadeArgs& sa, const FrameParams& fp) {
-    __shared__ uint32_t s_cnt[RT_BLOCK / RT_WAVE][6];  // per wave: alive, aux rays, refRays, paths, segments, emitter tests
-    __shared__ uint32_t s_base[2];
+    __shared__ uint32_t s_cnt[RT_BLOCK / RT_WAVE][8];  // per wave: alive, main rays, refRays, paths, segments, emitter tests, NEE rays, cosine probes
+    __shared__ uint32_t s_base[4];
     const uint32_t n = *sa.inCount;
     if (blockIdx.x * RT_BLOCK >= n) return;  // block-uniform
     const uint32_t gid = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -1621,14 +1643,16 @@ __device__ __forceinline__ void shade_block(const DevScene& sc, const PathState&
     const uint32_t wRef = wave_sum_u32(refRays), wPaths = wave_sum_u32(nPaths), wSeg = wave_sum_u32(path ? 1u : 0u), wEmit = wave_sum_u32(emitTests);
     const uint32_t wv = threadIdx.x / RT_WAVE;
     if (lane_id() == 0) {
-        s_cnt[wv][0] = nAlive; s_cnt[wv][1] = nM + nL + nC; s_cnt[wv][2] = wRef; s_cnt[wv][3] = wPaths; s_cnt[wv][4] = wSeg; s_cnt[wv][5] = wEmit;
+        s_cnt[wv][0] = nAlive; s_cnt[wv][1] = nM; s_cnt[wv][2] = wRef; s_cnt[wv][3] = wPaths; s_cnt[wv][4] = wSeg; s_cnt[wv][5] = wEmit; s_cnt[wv][6] = nL; s_cnt[wv][7] = nC;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tA = 0, tR = 0, tRef = 0, tP = 0, tS = 0, tE = 0;
-        for (int w = 0; w < RT_BLOCK / RT_WAVE; w++) { tA += s_cnt[w][0]; tR += s_cnt[w][1]; tRef += s_cnt[w][2]; tP += s_cnt[w][3]; tS += s_cnt[w][4]; tE += s_cnt[w][5]; }
+        uint32_t tA = 0, tR = 0, tRef = 0, tP = 0, tS = 0, tE = 0, tX = 0, tY = 0;
+        for (int w = 0; w < RT_BLOCK / RT_WAVE; w++) { tA += s_cnt[w][0]; tR += s_cnt[w][1]; tRef += s_cnt[w][2]; tP += s_cnt[w][3]; tS += s_cnt[w][4]; tE += s_cnt[w][5]; tX += s_cnt[w][6]; tY += s_cnt[w][7]; }
         s_base[0] = tA ? atomicAdd(sa.outActiveCount, tA) : 0u;
         s_base[1] = tR ? atomicAdd(sa.outRayCount, tR) : 0u;
+        s_base[2] = tX ? atomicAdd(RT_QUEUE_ORDER ? sa.outAuxCount2 : sa.outAuxCount, tX) : 0u;
+        s_base[3] = tY ? atomicAdd(RT_QUEUE_ORDER ? sa.outAuxCount : sa.outAuxCount2, tY) : 0u;
         atomicAdd(&sa.counters->raysReference, (unsigned long long)tRef);
         atomicAdd(&sa.counters->paths, (unsigned long long)tP);
         atomicAdd(&sa.counters->segments, (unsigned long long)tS);
@@ -1637,12 +1661,13 @@ __device__ __forceinline__ void shade_block(const DevScene& sc, const PathState&
     __syncthreads();
     if (alive) {
         uint32_t baseA = s_base[0], baseR = s_base[1];
-        for (uint32_t w = 0; w < wv; w++) { baseA += s_cnt[w][0]; baseR += s_cnt[w][1]; }
+        uint32_t baseX = (RT_QUEUE_ORDER ? 2u : 1u) * sa.auxOffset + s_base[2], baseY = (RT_QUEUE_ORDER ? 1u : 2u) * sa.auxOffset + s_base[3];
+        for (uint32_t w = 0; w < wv; w++) { baseA += s_cnt[w][0]; baseR += s_cnt[w][1]; baseX += s_cnt[w][6]; baseY += s_cnt[w][7]; }
         sa.outActive[baseA + lanes_below(mAlive)] = slot;
-        // per wave: main rays first, then its NEE rays, then its cosine probes
+        // the queue's pieces: main rays, NEE rays, cosine probes
         if (!(auxMask & 4u)) sa.outRays[baseR + lanes_below(mM)] = (slot << 2) | RAY_MAIN;
-        if (auxMask & 1u) sa.outRays[baseR + nM + lanes_below(mL)] = (slot << 2) | RAY_NEE;
-        if (auxMask & 2u) sa.outRays[baseR + nM + nL + lanes_below(mC)] = (slot << 2) | RAY_PROBE;
+        if (auxMask & 1u) sa.outRays[baseX + lanes_below(mL)] = (slot << 2) | RAY_NEE;
+        if (auxMask & 2u) sa.outRays[baseY + lanes_below(mC)] = (slot << 2) | RAY_PROBE;
     }
 }
 
@@ -1926,10 +1951,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_seed_rays(DevScene sc, PathState p
 // ---------------------------------------------------------------- misc kernels
 // start of a multi-kernel dispatch: n active paths and n rays in buffer 0, nothing in buffer 1, work counter 0
 __global__ void k_init_counts(uint32_t* counts, uint32_t n) {
-    if (threadIdx.x == 0) { counts[0] = n; counts[1] = 0; counts[2] = n; counts[3] = 0; counts[4] = 0; }
+    if (threadIdx.x == 0) { counts[0] = n; counts[1] = 0; counts[2] = n; counts[3] = 0; counts[4] = 0; counts[5] = 0; counts[6] = 0; counts[7] = 0; counts[8] = 0; }
 }
-__global__ void k_zero_counts(uint32_t* a, uint32_t* b, uint32_t* c) {
-    if (threadIdx.x == 0) { *a = 0; *b = 0; *c = 0; }
+__global__ void k_zero_counts(uint32_t* a, uint32_t* b, uint32_t* c, uint32_t* d, uint32_t* e) {
+    if (threadIdx.x == 0) { *a = 0; *b = 0; *c = 0; *d = 0; *e = 0; }
 }
 
 // Hash of the deterministic-math primitives over a fixed input table; the
