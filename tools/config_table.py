@@ -32,22 +32,24 @@ for name, key, W, H, spp, per in CONFIGS:
     r.render(pcw, W, H)
     for world in (1, 2, 4, 8):
         pc = cam(W, H, raysPerPixel=per, progressive=1, singleRender=0)
-        r.reset_counters()
-        r.sync()
-        t = time.perf_counter()
-        i, n = 0, spp // per
+        n = spp // per
         fif = 10 * world                     # as bench.py: at most 10 N dispatches (progressive frames) in flight on one of N GPUs
         ng = (n + fif - 1) // fif            # (rt_render_frames), in even groups
         sizes = [n // ng + (1 if j < n % ng else 0) for j in range(ng)]
-        for k in sizes:
-            pc.frameCount = i
-            if k == 1:
-                r.render(pc, W, H, row0=0, rowStride=world, sync=False)
-            else:
-                r.render_frames(pc, W, H, k, row0=0, rowStride=world, sync=False)
-            i += k
-        r.sync()
-        dt = time.perf_counter() - t
+        for timed in (False, True):          # the first group of a new shape allocates its path state: one untimed group first
+            r.reset_counters()
+            r.sync()
+            t = time.perf_counter()
+            i = 0
+            for k in (sizes if timed else sizes[:1]):
+                pc.frameCount = i
+                if k == 1:
+                    r.render(pc, W, H, row0=0, rowStride=world, sync=False)
+                else:
+                    r.render_frames(pc, W, H, k, row0=0, rowStride=world, sync=False)
+                i += k
+            r.sync()
+            dt = time.perf_counter() - t
         c = r.counters()
         alg = 32.0 * c["boxTests"] + 36.0 * c["triTests"] + 100.0 * c["raysHit"]
         print(f"| {name} ({label}) {W}x{H} | {world} | {spp} | {dt * 1e3:.1f} ms | {c['raysReference'] / dt / 1e6:.0f} | {c['raysTraced'] / dt / 1e6:.0f} | "
