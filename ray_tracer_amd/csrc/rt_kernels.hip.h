@@ -148,7 +148,7 @@ struct PathState {
     __host__ __device__ __forceinline__ float4* arr(uint32_t k) const { return base + (size_t)k * pitch; }
     __host__ __device__ __forceinline__ float4* rayO() const { return arr(0); }        // main ray origin            | w: misWeight (raytrace.comp:487)
     __host__ __device__ __forceinline__ float4* rayD() const { return arr(1); }        // main ray direction         | w: RNG state bits (:564)
-    __host__ __device__ __forceinline__ float4* auxO() const { return arr(2); }        // origin of the probe rays   | w: max(0, dot(n, lightSample))          (:460)
+    __host__ __device__ __forceinline__ float4* auxO() const { return arr(2); }        // origin of the probe rays (read by the traversal only)
     __host__ __device__ __forceinline__ float4* auxDL() const { return arr(3); }       // NEE direction              | w: cosineHemispherePDF(n, lightSample)  (:448)
     __host__ __device__ __forceinline__ float4* auxDC() const { return arr(4); }       // cosine-sample direction    | w: cosineHemispherePDF(n, cosineSample) (:454)
     __host__ __device__ __forceinline__ float4* hit(uint32_t kind) const { return arr(5 + kind); }  // per ray kind. From the ray's creator: {closest sphere hit, its object bits, object mask, tE of a light query or 0}; from the traversal: {dst, object bits, triangle bits, 0}
@@ -156,7 +156,7 @@ struct PathState {
     __host__ __device__ __forceinline__ float4* total() const { return arr(9); }       // totalColor                 | w: samples finished for this pixel
     // (directLight has no record: between two segments it is either about to be recomputed from the probe results — bit 31 of
     // att.w — or one of two constants: -1 after a specular bounce, bit 30, and 0 at the start of a sample)
-    __host__ __device__ __forceinline__ float4* pendAlbedo() const { return arr(10); } // albedo of the previous diffuse hit
+    __host__ __device__ __forceinline__ float4* pendAlbedo() const { return arr(10); } // albedo of the previous diffuse hit | w: max(0, dot(n, lightSample)) (:460)
     __host__ __device__ __forceinline__ float4* accum() const { return arr(11); }      // sum of trace() over the pixel's samples (:572)
     __host__ __device__ __forceinline__ float4* camHit() const { return arr(12); }     // the camera ray's hit record, kept from the pixel's first sample (FrameParams::camReuse)
     __host__ __device__ __forceinline__ float4* camDir() const { return arr(13); }     // the camera ray's direction (every sample of the pixel starts with it: no jitter, raytrace.comp:541-557)
@@ -1416,7 +1416,7 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
             float4 hL = make_float4(RT_MISS_DST, __uint_as_float(RT_HIT_NONE), 0.f, 0.f), hC = hL;
             if (!(jraw & 0x20000000u)) hL = ps.hit(RAY_NEE)[slot];
             if (!(jraw & 0x10000000u)) hC = ps.hit(RAY_PROBE)[slot];
-            const float4 aO = ps.auxO()[slot], aL = ps.auxDL()[slot], aC = ps.auxDC()[slot];
+            const float4 aL = ps.auxDL()[slot], aC = ps.auxDC()[slot];
             float tL = hL.x, tC = hC.x;
             uint32_t oL = __float_as_uint(hL.y), oC = __float_as_uint(hC.y);
             rt_vec3 dL = f4xyz(aL), dC = f4xyz(aC);
@@ -1430,10 +1430,11 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
             float realCosinePDF = aC.w;
             float misWeight2 = realCosinePDF * realCosinePDF / (lightPDF * lightPDF + realCosinePDF * realCosinePDF);
             if (rt_isnan(misWeight2)) misWeight2 = 0.f;
-            rt_vec3 albedo = f4xyz(ps.pendAlbedo()[slot]);
+            const float4 pA = ps.pendAlbedo()[slot];   // {albedo, max(0, dot(n, lightSample))}
+            rt_vec3 albedo = f4xyz(pA);
             rt_vec3 dl = rt_scale(rt_v3(lmE.x, lmE.y, lmE.z), lmE.w);
             float k = (realLightPDF == 0.f) ? 0.f : misWeight1 / realLightPDF;
-            rt_vec3 f = rt_scale(rt_scale(rt_scale(albedo, RT_INV_PI), aO.w), k);
+            rt_vec3 f = rt_scale(rt_scale(rt_scale(albedo, RT_INV_PI), pA.w), k);
             direct = rt_mul(dl, f);
             misW = misWeight2;
         }
@@ -1600,10 +1601,10 @@ __device__ __forceinline__ void shade_path(const DevScene& sc, const PathState& 
             } else {
                 if (auxMask & 1u) ps.hit(RAY_NEE)[slot] = sL;     // the traversal's seed; an answered query needs no record (att.w bits 29 / 28)
                 if (auxMask & 2u) ps.hit(RAY_PROBE)[slot] = sC;
-                ps.auxO()[slot] = mk4(auxOrigin, auxNdotL);
+                ps.auxO()[slot] = mk4(auxOrigin, 0.f);
                 ps.auxDL()[slot] = mk4(auxL, auxCosPdfL);
                 ps.auxDC()[slot] = mk4(auxC, auxCosPdfC);
-                ps.pendAlbedo()[slot] = mk4(auxAlbedo, 0.f);
+                ps.pendAlbedo()[slot] = mk4(auxAlbedo, auxNdotL);
             }
         }
         const uint32_t answered = wantAux ? (((auxMask & 1u) ? 0u : 0x20000000u) | ((auxMask & 2u) ? 0u : 0x10000000u)) : 0u;
