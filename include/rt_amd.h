@@ -371,8 +371,9 @@ int  rt_get_trace_busy_ms(rt_ctx* ctx, double* msOut);
  *                    from and joined to the ctx stream), so that one part's shading kernel and the draining tail of its
  *                    traversal launch run under the other parts' traversal; 1..4; 0 (default) = 3, except one for
  *                    dispatches of >= 8 M paths of scenes whose long rays walk into many placed objects (they lose by it)
- *   "lane_grid_pct"  ... each part's traversal launch taking this share of the resident work-groups (default 50: three parts
- *                    oversubscribe the GPU 1.5 times, so a part in its shading kernel leaves no traversal slot empty).
+ *   "lane_grid_pct"  ... each part's traversal launch taking this share of the resident work-groups (10..100; 0 = default: 50 —
+ *                    three parts oversubscribe the GPU 1.5 times, so a part in its shading kernel leaves no traversal slot
+ *                    empty — and 40 for parts of fewer than 1.2 M paths).
  *                    The parts only overlap while their streams sit on different hardware queues: ROCm deals a process's
  *                    streams onto GPU_MAX_HW_QUEUES queues (default 4); a host with many streams of its own should start
  *                    with that variable raised (bench.py sets 8)

@@ -20,7 +20,7 @@ def forced_parts(renderer):
     renderer.set_tuning("pipeline", 0)
     renderer.set_tuning("lanes_min_kslots", 1)
     yield renderer
-    for k, v in (("pipeline", -1), ("lanes_min_kslots", 1024), ("lanes", 0), ("lane_grid_pct", 50), ("lds_stack", 24)):
+    for k, v in (("pipeline", -1), ("lanes_min_kslots", 1024), ("lanes", 0), ("lane_grid_pct", 0), ("lds_stack", 24)):
         renderer.set_tuning(k, v)
 
 
